@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- exact-GP fit+predict throughput on MI355X (BASELINE.json metric).
+
+One "step" = one whole fit+predict at one hyper-parameter setting on inputs that are
+already resident in HBM: gram(x,x) -> blocked Cholesky -> log-marginal -> gram(x*,x)
+-> posterior mean/variance (gpax's ExactGP: _gp_prior's MVN log-prob, gpax/gp.py:145-151,
+plus _fast_predict, gpax/gp.py:464-484).  Workload at every N: BASELINE.json configs[1]
+("ExactGP RBF d=8, N=4096 fp64 on one MI355X"), M=1000 test points, synthetic inputs of
+SURVEY.md section 8(d).
+
+Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the path shards
+over independent hyper-parameter draws (gpax's vmap over hp samples, gpax/gp.py:384-390):
+rank r factorises its own draw on its own GPU, no data-path collective, weak scaling.
+torch.distributed (gloo) is used only for the barrier and the max-over-ranks clock.
+
+Prints ONE JSON line (rank 0).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet fp64 matrix (= vector) peak; tools/peaks measures the achievable rate
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def synthetic_problem(n, d, m, seed=0):
+    """Deterministic inputs of SURVEY.md section 8(d) (same recipe as oracle.synthetic_problem;
+    restated here so the timed path never imports the oracle)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1.0, 1.0, (n, d))
+    x_new = rng.uniform(-1.0, 1.0, (m, d))
+    y_raw = np.sin(3.0 * x.sum(1) / math.sqrt(d)) + 0.1 * rng.standard_normal(n)
+    y = (y_raw - y_raw.mean()) / (y_raw.std() + 1e-8)
+    return x, y, x_new
+
+
+def hp_draw(rank):
+    """Hyper-parameter draw handled by this rank.  Rank 0 uses the prior medians
+    (k_scale=1, k_length=1, k_noise=HalfNormal(0.01) median, k_jitter=1e-6; gpax/kernels.py:69-75,
+    101-107); other ranks use fixed quantile draws of the same priors (independent units)."""
+    k_noise = 0.006744897501960818
+    if rank == 0:
+        return 1.0, 1.0, k_noise
+    rng = np.random.default_rng(1000 + rank)
+    return float(np.exp(0.3 * rng.standard_normal())), float(np.exp(0.3 * rng.standard_normal())), k_noise
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--m", type=int, default=1000)
+    ap.add_argument("--kind", default="rbf", choices=["rbf", "matern52"])
+    ap.add_argument("--nb", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+
+    import torch  # plumbing only: device-wide synchronize + torch.distributed barrier / MAX
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+
+    import gpax_amd  # raises if libgpx_hip.so is missing: no fallback
+
+    core = gpax_amd.Core(local_rank)
+    if args.nb:
+        core.set_option("nb", args.nb)
+    n, d, m = args.n, args.d, args.m
+    kind = gpax_amd.RBF if args.kind == "rbf" else gpax_amd.MATERN52
+    x, y, x_new = synthetic_problem(n, d, m, seed=0)
+    k_scale, k_length, k_noise = hp_draw(rank)
+    params = gpax_amd.make_params(kind, k_scale, k_length, None, np.array([k_noise]), 1e-6, True)
+    core.set_train(x)            # jax.device_put(x) analogue: inputs resident in HBM before the clock starts
+    core.set_test(x_new)
+    core.set_targets(y - 1.0, np.ones(m))   # ConstantMean() = 1.0 (gpax/means.py:75)
+
+    def step():
+        core.fit_predict_async(params, 0.0)
+        return core.fetch_results()  # logp, mean, var back on the host (16 KB), as _fast_predict returns them
+
+    def sync():
+        core.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info, logp, mean, var = step()
+    sync()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert info == 0 and np.isfinite(logp) and np.isfinite(mean).all() and (var > 0).all()
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n * world * args.steps / elapsed  # training points factorised + predicted from, per second, whole job
+
+    out = {
+        "metric": "exact-GP fit+predict points/sec (NxN RBF, fp64)",
+        "value": value,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"ExactGP {args.kind.upper()} d={d}, N={n} train / M={m} test, fp64: gram + Cholesky + log-marginal + posterior mean/var per step",
+            "n": n, "d": d, "m": m, "nb": core.get_option("nb"),
+            "parallelism": f"hp-draw x{world} (independent factorisations, no collective)",
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel (trailing SYRK/GEMM update on fp64 MFMA), measured with
+        # HIP events on the library's own streams over a second pass of the same K steps (event
+        # brackets on every launch perturb the clock, so they are kept out of `value`'s region).
+        core.profile_reset()
+        core.profile_mode(1)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        prof_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
+        stages = {gpax_amd._lib.STAGE_NAMES[i]: core.profile_get(i) for i in range(7)}
+        core.profile_mode(0)
+        tr = stages["trailing_update"]
+        avg_s = tr["ms"] * 1e-3 / max(tr["launches"], 1)
+        flops_per_launch = tr["flops"] / max(tr["launches"], 1)
+        achieved = flops_per_launch / avg_s * 1e-12 if avg_s > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "gemm_nt_kernel (trailing SYRK/GEMM update, v_mfma_f64_16x16x4_f64)",
+            "bound": "mfma",
+            "achieved": achieved,
+            "peak": FP64_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+            "traffic": None,
+            "launches_per_step": tr["launches"] / args.steps,
+            "avg_launch_us": avg_s * 1e6,
+            "algorithmic_flops_per_launch": flops_per_launch,
+        }
+        gr = stages["gram"]
+        g_avg = gr["ms"] * 1e-3 / max(gr["launches"], 1)
+        g_bytes = gr["bytes"] / max(gr["launches"], 1)
+        out["roofline_gram"] = {
+            "kernel": "gram_kernel (tiled pairwise distance + RBF epilogue)",
+            "bound": "hbm",
+            "achieved": g_bytes / g_avg * 1e-9 if g_avg > 0 else 0.0,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": (g_bytes / g_avg * 1e-9 / HBM_PEAK_GBS) if g_avg > 0 else 0.0,
+            "traffic": None,
+            "avg_launch_us": g_avg * 1e6,
+        }
+        out["stage_ms_per_step"] = {k: v["ms"] / args.steps for k, v in stages.items()}
+        out["ms_per_step_profiled"] = prof_ms_per_step
+
+        if not args.no_cpu_baseline:
+            # ---- CPU baseline: the oracle (NumPy/SciPy port of the reference formulae; the reference's
+            # JAX path is not installable here) on the host cores, bounded sample of the same workload.
+            from oracle import gp_oracle as orc
+
+            p = {
+                "k_scale": np.array([k_scale]), "k_length": np.array([k_length]),
+                "k_noise": np.array([k_noise]), "k_jitter": np.array([1e-6]),
+            }
+            times = []
+            for _ in range(args.cpu_reps):
+                c0 = time.perf_counter()
+                logp_ref, mean_ref, var_ref = orc.fit_predict(kind, x, y, x_new, p)
+                times.append(time.perf_counter() - c0)
+            t_cpu = float(np.median(times))
+            out["cpu_baseline"] = {
+                "value": n / t_cpu,
+                "unit": "points/s",
+                "cores": os.cpu_count(),
+                "kind": "port",
+                "sample": f"{args.cpu_reps} full steps of the same workload (N={n}, d={d}, M={m}), median; "
+                          f"NumPy/SciPy -> OpenBLAS dpotrf/dtrsm on all host cores",
+                "ms_per_step": t_cpu * 1e3,
+            }
+            out["parity_vs_cpu"] = {
+                "logp_rel": abs(logp - logp_ref) / abs(logp_ref),
+                "mean_maxabs": float(np.abs(mean - mean_ref).max()),
+                "var_maxabs": float(np.abs(var - var_ref).max()),
+            }
+        print(json.dumps(out))
+    core.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

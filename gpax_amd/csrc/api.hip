@@ -1,0 +1,721 @@
+// api.hip -- C ABI (include/gpx.h) and the host-side drivers of the HIP path:
+// the bordered right-looking blocked Cholesky with two-stream look-ahead, the
+// solves against a cached factor, and the measurement hooks.
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "gpx_internal.h"
+
+static std::string g_create_error;
+
+void gpx_set_error(gpx_handle* h, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+}
+
+// --------------------------------------------------------------------------- memory
+
+template <typename T>
+static int ensure(gpx_handle* h, T** p, int64_t* cap, int64_t count) {
+  if (count <= *cap && *p) return GPX_OK;
+  if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+  if (count <= 0) count = 1;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
+  if (e != hipSuccess) {
+    gpx_set_error(h, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    *p = nullptr;
+    return GPX_ERR_NOMEM;
+  }
+  *cap = count;
+  return GPX_OK;
+}
+
+static int ensure_pinned(gpx_handle* h, int64_t count) {
+  if (count <= h->pinned_cap && h->h_pinned) return GPX_OK;
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  h->h_pinned = nullptr; h->pinned_cap = 0;
+  GPX_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), (size_t)count * sizeof(double), 0));
+  h->pinned_cap = count;
+  return GPX_OK;
+}
+
+// ------------------------------------------------------------------------ profiling
+
+static hipEvent_t prof_event(gpx_handle* h) {
+  if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+
+void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double bytes) {
+  if (!h->prof_mode) return;
+  gpx_handle::PendingEv p;
+  p.stage = stage; p.a = prof_event(h); p.b = prof_event(h);
+  (void)hipEventRecord(p.a, s);
+  h->pending.push_back(p);
+  h->prof[stage].flops += flops;
+  h->prof[stage].bytes += bytes;
+  h->prof[stage].launches += 1;
+}
+
+void prof_end(gpx_handle* h, hipStream_t s) {
+  if (!h->prof_mode) return;
+  (void)hipEventRecord(h->pending.back().b, s);
+}
+
+static int prof_collect(gpx_handle* h) {
+  if (h->pending.empty()) return GPX_OK;
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_trail));
+  for (auto& p : h->pending) {
+    float ms = 0.f;
+    GPX_HIP_CHECK(h, hipEventElapsedTime(&ms, p.a, p.b));
+    h->prof[p.stage].ms += ms;
+    h->ev_pool.push_back(p.a);
+    h->ev_pool.push_back(p.b);
+  }
+  h->pending.clear();
+  return GPX_OK;
+}
+
+// -------------------------------------------------------------------- create/destroy
+
+extern "C" int gpx_abi_version(void) { return GPX_ABI_VERSION; }
+
+extern "C" int gpx_create(int device_id, gpx_handle** out) {
+  if (!out) return GPX_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("no HIP device: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0");
+    return GPX_ERR_HIP;
+  }
+  if (device_id < 0 || device_id >= ndev) { g_create_error = "device_id out of range"; return GPX_ERR_ARG; }
+  gpx_handle* h = new gpx_handle();
+  h->device = device_id;
+  if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&h->prop, device_id)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipStreamCreateWithFlags(&h->s_trail, hipStreamNonBlocking)) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&h->d_scal), 8 * sizeof(double))) != hipSuccess ||
+      (e = hipMalloc(reinterpret_cast<void**>(&h->d_info), 4 * sizeof(int))) != hipSuccess) {
+    g_create_error = std::string("gpx_create: ") + hipGetErrorString(e);
+    delete h;
+    return GPX_ERR_HIP;
+  }
+  if (strncmp(h->prop.gcnArchName, "gfx950", 6) != 0) {
+    // The code object is gfx950-only; say so instead of failing at the first launch.
+    g_create_error = std::string("gpx_create: device is ") + h->prop.gcnArchName + ", this library is built for gfx950";
+    delete h;
+    return GPX_ERR_UNSUPPORTED;
+  }
+  const char* env;
+  if ((env = getenv("GPX_NB"))) h->nb = atoi(env) == 64 ? 64 : 128;
+  if ((env = getenv("GPX_LOOKAHEAD"))) h->lookahead = atoi(env) != 0;
+  *out = h;
+  return GPX_OK;
+}
+
+extern "C" int gpx_destroy(gpx_handle* h) {
+  if (!h) return GPX_OK;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  void* bufs[] = {h->d_x, h->d_xnew, h->d_r, h->d_mnew, h->d_hyp, h->d_noise, h->d_A, h->d_L, h->d_W,
+                  h->d_S, h->d_cov, h->d_z, h->d_scal, h->d_info, h->d_mean, h->d_g1, h->d_g2,
+                  h->d_gout, h->d_vec};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  for (auto e : h->ev_panel) (void)hipEventDestroy(e);
+  for (auto e : h->ev_trail) (void)hipEventDestroy(e);
+  for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  if (h->s_main) (void)hipStreamDestroy(h->s_main);
+  if (h->s_trail) (void)hipStreamDestroy(h->s_trail);
+  delete h;
+  return GPX_OK;
+}
+
+extern "C" const char* gpx_last_error(const gpx_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int gpx_device_name(gpx_handle* h, char* buf, int len) {
+  if (!h || !buf || len <= 0) return GPX_ERR_ARG;
+  snprintf(buf, (size_t)len, "%s (%s, %d CUs)", h->prop.name, h->prop.gcnArchName, h->prop.multiProcessorCount);
+  return GPX_OK;
+}
+
+extern "C" int gpx_synchronize(gpx_handle* h) {
+  if (!h) return GPX_ERR_ARG;
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_trail));
+  return GPX_OK;
+}
+
+extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
+  if (!h || !name) return GPX_ERR_ARG;
+  if (!strcmp(name, "nb")) {
+    if (value != 64 && value != 128) { gpx_set_error(h, "nb must be 64 or 128"); return GPX_ERR_ARG; }
+    if (h->nb != (int)value) { h->nb = (int)value; h->have_factor = false; }
+    return GPX_OK;
+  }
+  if (!strcmp(name, "lookahead")) { h->lookahead = value != 0; return GPX_OK; }
+  if (!strcmp(name, "graph")) { h->use_graph = value != 0; return GPX_OK; }
+  gpx_set_error(h, std::string("unknown option ") + name);
+  return GPX_ERR_ARG;
+}
+
+extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
+  if (!h || !name || !value) return GPX_ERR_ARG;
+  if (!strcmp(name, "nb")) { *value = h->nb; return GPX_OK; }
+  if (!strcmp(name, "lookahead")) { *value = h->lookahead; return GPX_OK; }
+  if (!strcmp(name, "graph")) { *value = h->use_graph; return GPX_OK; }
+  gpx_set_error(h, std::string("unknown option ") + name);
+  return GPX_ERR_ARG;
+}
+
+// ------------------------------------------------------------------ hyper-parameters
+
+// Validate the keyword block against (n rows, d dims) and upload length[d], period[d]
+// (and the per-row noise vector when n_noise == n) to the device.
+static int upload_params(gpx_handle* h, hipStream_t s, const gpx_kernel_params* p, int64_t n, int d,
+                         const double** noise_dev, double* noise_scalar) {
+  if (!p) { gpx_set_error(h, "params is NULL"); return GPX_ERR_ARG; }
+  if (p->kind != GPX_RBF && p->kind != GPX_MATERN52 && p->kind != GPX_PERIODIC) {
+    gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
+  }
+  if (!p->k_length || (p->n_length != 1 && p->n_length != d)) {
+    gpx_set_error(h, "k_length must have 1 or d entries"); return GPX_ERR_ARG;
+  }
+  if (p->kind == GPX_PERIODIC && (!p->k_period || (p->n_period != 1 && p->n_period != d))) {
+    // the reference class defines no k_period Parameter (gpax/kernels.py:150-168): it must be passed
+    gpx_set_error(h, "periodic kernel needs k_period with 1 or d entries"); return GPX_ERR_ARG;
+  }
+  if (p->n_noise != 0 && p->n_noise != 1 && p->n_noise != n) {
+    gpx_set_error(h, "k_noise must have 0, 1 or n entries"); return GPX_ERR_ARG;
+  }
+  if (p->n_noise > 0 && !p->k_noise) { gpx_set_error(h, "k_noise is NULL"); return GPX_ERR_ARG; }
+  std::vector<double> hyp(2 * (size_t)d);
+  for (int k = 0; k < d; ++k) {
+    hyp[k] = p->k_length[p->n_length == 1 ? 0 : k];
+    hyp[d + k] = (p->kind == GPX_PERIODIC) ? p->k_period[p->n_period == 1 ? 0 : k] : 1.0;
+  }
+  GPX_RET(ensure(h, &h->d_hyp, &h->hyp_cap, 2 * (int64_t)d));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_hyp, hyp.data(), hyp.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  *noise_dev = nullptr;
+  *noise_scalar = 0.0;
+  if (p->n_noise == 1) *noise_scalar = p->k_noise[0];
+  else if (p->n_noise > 1) {
+    GPX_RET(ensure(h, &h->d_noise, &h->noise_cap, n));
+    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_noise, p->k_noise, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    *noise_dev = h->d_noise;
+  }
+  return GPX_OK;
+}
+
+// k(x, x) without the diagonal rule: the kernel formulae at r2 = 0 (Matern keeps the 1e-12).
+static double kernel_diag_value(int kind, double k_scale) {
+  if (kind == GPX_MATERN52) {
+    const double a = 2.2360679774997896964 * sqrt(1e-12);
+    return k_scale * (1.0 + a) * exp(-a);
+  }
+  return k_scale;
+}
+
+static double gram_flops_per_entry(int kind, int d) {
+  // direct differences: 2 flop (sub, fma) per dimension (+ sin ~ 40 for periodic), exp ~ 40, Matern + sqrt
+  double f = (kind == GPX_PERIODIC ? 44.0 : 2.0) * d + 42.0;
+  if (kind == GPX_MATERN52) f += 30.0;
+  return f;
+}
+
+// ---------------------------------------------------------------------------- gram
+
+extern "C" int gpx_gram(gpx_handle* h, const gpx_kernel_params* p, const double* x1, int64_t n1,
+                        const double* x2, int64_t n2, int32_t d, double* out) {
+  if (!h) return GPX_ERR_ARG;
+  if (!p || !x1 || !x2 || !out || n1 < 0 || n2 < 0 || d <= 0) { gpx_set_error(h, "gpx_gram: bad argument"); return GPX_ERR_ARG; }
+  if (n1 == 0 || n2 == 0) return GPX_OK;  // empty output
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  hipStream_t s = h->s_main;
+  const bool diag = p->apply_noise && n1 == n2;  // gpax/kernels.py:124
+  const double* noise_dev; double noise_scalar;
+  gpx_kernel_params q = *p;
+  if (!diag) q.n_noise = 0;  // the noise vector is only meaningful under the diagonal rule
+  GPX_RET(upload_params(h, s, &q, n1, d, &noise_dev, &noise_scalar));
+  GPX_RET(ensure(h, &h->d_g1, &h->g1_cap, n1 * d));
+  GPX_RET(ensure(h, &h->d_g2, &h->g2_cap, n2 * d));
+  GPX_RET(ensure(h, &h->d_gout, &h->gout_cap, n1 * n2));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_g1, x1, (size_t)(n1 * d) * sizeof(double), hipMemcpyHostToDevice, s));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_g2, x2, (size_t)(n2 * d) * sizeof(double), hipMemcpyHostToDevice, s));
+  GramLaunch g;
+  g.kind = p->kind; g.d = d; g.k_scale = p->k_scale; g.hyp = h->d_hyp;
+  g.x1 = h->d_g1; g.x2 = h->d_g2; g.n1 = n1; g.n2 = n2; g.out = h->d_gout; g.ld = n2;
+  g.lower_only = 0; g.diag_rule = diag ? 1 : 0; g.noise = noise_dev; g.noise_scalar = noise_scalar;
+  g.jitter = p->k_jitter;
+  prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(p->kind, d) * n1 * n2, 8.0 * n1 * n2 + 8.0 * (n1 + n2) * d);
+  GPX_RET(launch_gram(h, s, g));
+  prof_end(h, s);
+  GPX_HIP_CHECK(h, hipMemcpyAsync(out, h->d_gout, (size_t)(n1 * n2) * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(s));
+  return GPX_OK;
+}
+
+// ------------------------------------------------------------------- resident inputs
+
+extern "C" int gpx_set_train(gpx_handle* h, const double* x, int64_t n, int32_t d) {
+  if (!h) return GPX_ERR_ARG;
+  if (!x || n <= 0 || d <= 0) { gpx_set_error(h, "gpx_set_train: need x (n>0, d>0)"); return GPX_ERR_ARG; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  GPX_RET(ensure(h, &h->d_x, &h->x_cap, n * d));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_x, x, (size_t)(n * d) * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  if (h->d != d) { h->m = 0; }
+  h->n = n; h->d = d;
+  h->have_factor = false; h->have_z = false; h->have_r = false;
+  return GPX_OK;
+}
+
+extern "C" int gpx_set_test(gpx_handle* h, const double* x_new, int64_t m) {
+  if (!h) return GPX_ERR_ARG;
+  if (h->d <= 0) { gpx_set_error(h, "gpx_set_test: call gpx_set_train first (d unknown)"); return GPX_ERR_STATE; }
+  if (m < 0 || (m > 0 && !x_new)) { gpx_set_error(h, "gpx_set_test: bad argument"); return GPX_ERR_ARG; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  if (m > 0) {
+    GPX_RET(ensure(h, &h->d_xnew, &h->xnew_cap, m * h->d));
+    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_xnew, x_new, (size_t)(m * h->d) * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+    GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  }
+  h->m = m;
+  h->have_mnew = false;
+  return GPX_OK;
+}
+
+extern "C" int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const double* m_new) {
+  if (!h) return GPX_ERR_ARG;
+  if (h->n <= 0) { gpx_set_error(h, "gpx_set_targets: call gpx_set_train first"); return GPX_ERR_STATE; }
+  if (!y_minus_m) { gpx_set_error(h, "gpx_set_targets: y_minus_m is NULL"); return GPX_ERR_ARG; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  GPX_RET(ensure(h, &h->d_r, &h->r_cap, h->n));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+  h->have_r = true;
+  h->have_mnew = false;
+  if (m_new && h->m > 0) {
+    GPX_RET(ensure(h, &h->d_mnew, &h->mnew_cap, h->m));
+    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_mnew, m_new, (size_t)h->m * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+    h->have_mnew = true;
+  }
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  return GPX_OK;
+}
+
+// ------------------------------------------------------------- bordered factorisation
+
+static int ensure_events(gpx_handle* h, size_t nblk) {
+  while (h->ev_panel.size() < nblk) {
+    hipEvent_t a, b;
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    h->ev_panel.push_back(a);
+    h->ev_trail.push_back(b);
+  }
+  return GPX_OK;
+}
+
+// Right-looking blocked Cholesky of the (npad x npad) matrix in d_A with `rows - npad`
+// border rows riding along (they are only ever "rows below the panel").  Results in d_L.
+//   step k:  potrf_diag  A_kk -> L_kk, W_k = inv(L_kk)            (one workgroup, LDS resident)
+//            panel       L_ik = A_ik W_k^T      for all rows below  (MFMA GEMM)
+//            look-ahead  column block k+1 of the trailing matrix   (MFMA GEMM, same stream)
+//            trailing    the rest of the trailing matrix           (MFMA GEMM, second stream)
+// so the next panel overlaps the bulk of this step's trailing update.
+static int factor_loop(gpx_handle* h, int64_t rows) {
+  const int64_t nb = h->nb, npad = h->npad, ld = h->ld;
+  const int64_t nblk = npad / nb;
+  hipStream_t P = h->s_main, T = h->lookahead ? h->s_trail : h->s_main;
+  GPX_RET(ensure_events(h, (size_t)nblk));
+  double* A = h->d_A; double* L = h->d_L;
+  std::vector<char> trail_pending((size_t)nblk, 0);
+  for (int64_t k = 0; k < nblk; ++k) {
+    const int64_t c0 = k * nb, r0 = c0 + nb;
+    prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
+    GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
+                              h->d_info, (int)c0));
+    prof_end(h, P);
+    const int64_t mrows = rows - r0;
+    if (mrows <= 0) continue;
+    GemmLaunch g;
+    g.A = A + r0 * ld + c0; g.lda = ld;
+    g.B = h->d_W + k * nb * nb; g.ldb = nb;
+    g.C = L + r0 * ld + c0; g.ldc = ld;
+    g.M = mrows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+    g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+    prof_begin(h, P, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
+    GPX_RET(launch_gemm_nt(h, P, g));
+    prof_end(h, P);
+    if (k + 1 >= nblk) continue;
+    // look-ahead: column block k+1 (rows r0.., columns r0..r0+nb)
+    if (h->lookahead && k >= 1 && trail_pending[(size_t)(k - 1)])
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_trail[(size_t)(k - 1)], 0));
+    GemmLaunch u;
+    u.A = L + r0 * ld + c0; u.lda = ld;
+    u.B = L + r0 * ld + c0; u.ldb = ld;
+    u.C = A + r0 * ld + r0; u.ldc = ld;
+    u.M = mrows; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
+    u.lower = 1; u.row_off = r0; u.col_off = r0; u.b_lower_tri = 0; u.small_tile = 1;
+    prof_begin(h, P, GPX_STAGE_TRAILING, 2.0 * (mrows - nb / 2.0) * nb * nb, 8.0 * (2.0 * mrows * nb + mrows * nb));
+    GPX_RET(launch_gemm_nt(h, P, u));
+    prof_end(h, P);
+    const int64_t ncols = npad - r0 - nb;
+    if (ncols <= 0) continue;
+    const int64_t r1 = r0 + nb, mr = rows - r1;
+    if (h->lookahead) {
+      GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], P));
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
+    }
+    GemmLaunch t;
+    t.A = L + r1 * ld + c0; t.lda = ld;
+    t.B = L + r1 * ld + c0; t.ldb = ld;
+    t.C = A + r1 * ld + r1; t.ldc = ld;
+    t.M = mr; t.N = ncols; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
+    t.lower = 1; t.row_off = r1; t.col_off = r1; t.b_lower_tri = 0; t.small_tile = 0;
+    // algorithmic work: the lower trapezoid of (mr x ncols) entries, 2*nb flop each
+    const double entries = (double)ncols * (ncols + 1) / 2.0 + (double)(mr - ncols) * ncols;
+    prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(mr + ncols) * nb));
+    GPX_RET(launch_gemm_nt(h, T, t));
+    prof_end(h, T);
+    if (h->lookahead) {
+      GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
+      trail_pending[(size_t)k] = 1;
+    }
+  }
+  return GPX_OK;
+}
+
+// Build [K ; k_cross ; r] in d_A, factorise, leave [L ; V^T ; z^T] in d_L.
+static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_rows, bool with_r, double* K_out) {
+  if (h->n <= 0 || !h->d_x) { gpx_set_error(h, "no training inputs: call gpx_set_train first"); return GPX_ERR_STATE; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  const int64_t n = h->n, nb = h->nb; const int d = h->d;
+  const int64_t npad = round_up(n, nb);
+  const int64_t E = m_rows + (with_r ? 1 : 0);
+  const int64_t epad = E > 0 ? round_up(E, 64) : 0;
+  const int64_t rows = npad + epad, ld = npad;
+  hipStream_t s = h->s_main;
+  GPX_RET(ensure(h, &h->d_A, &h->a_cap, rows * ld));
+  GPX_RET(ensure(h, &h->d_L, &h->l_cap, rows * ld));
+  GPX_RET(ensure(h, &h->d_W, &h->w_cap, npad * nb));
+  GPX_RET(ensure(h, &h->d_z, &h->z_cap, npad));
+  h->have_factor = false; h->have_z = false;
+  h->npad = npad; h->epad = epad; h->ld = ld;
+
+  const double* noise_dev; double noise_scalar;
+  GPX_RET(upload_params(h, s, p, n, d, &noise_dev, &noise_scalar));
+
+  // K (diagonal rule always on for k_train: gpax/gp.py:293 calls f(x, x, k_noise, k_jitter))
+  GramLaunch g;
+  g.kind = p->kind; g.d = d; g.k_scale = p->k_scale; g.hyp = h->d_hyp;
+  g.x1 = h->d_x; g.x2 = h->d_x; g.n1 = n; g.n2 = n; g.out = h->d_A; g.ld = ld;
+  g.lower_only = K_out ? 0 : 1; g.diag_rule = p->apply_noise ? 1 : 0;
+  g.noise = noise_dev; g.noise_scalar = noise_scalar; g.jitter = p->k_jitter;
+  {
+    const double T = (double)((n + 63) / 64);
+    const double entries = K_out ? (double)n * n : T * (T + 1) / 2.0 * 4096.0;
+    prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(p->kind, d) * entries, 8.0 * entries + 16.0 * n * d);
+    GPX_RET(launch_gram(h, s, g));
+    prof_end(h, s);
+  }
+  if (K_out) {
+    GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
+                                      (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
+  }
+  GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
+  if (m_rows > 0) {
+    GramLaunch c = g;
+    c.x1 = h->d_xnew; c.n1 = m_rows; c.out = h->d_A + npad * ld; c.lower_only = 0; c.diag_rule = 0;
+    c.noise = nullptr; c.noise_scalar = 0.0;
+    prof_begin(h, s, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(p->kind, d) * m_rows * n,
+               8.0 * m_rows * n + 8.0 * (m_rows + n) * d);
+    GPX_RET(launch_gram(h, s, c));
+    prof_end(h, s);
+  }
+  if (with_r) GPX_RET(launch_set_row(h, s, h->d_A + (npad + m_rows) * ld, h->d_r, n, npad));
+  GPX_RET(launch_fill_rect(h, s, h->d_A, ld, npad + E, rows, 0, n, 0.0));  // unused border rows
+  GPX_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
+
+  GPX_RET(factor_loop(h, rows));
+
+  h->have_factor = true;
+  h->m_in_factor = m_rows; h->r_in_factor = with_r;
+  h->f_kind = p->kind; h->f_scale = p->k_scale; h->f_jitter = p->k_jitter;
+  h->f_length.assign(p->k_length, p->k_length + p->n_length);
+  h->f_period.clear();
+  if (p->kind == GPX_PERIODIC) h->f_period.assign(p->k_period, p->k_period + p->n_period);
+  if (with_r) {  // keep z = L^-1 r for later posterior calls against the cached factor
+    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_z, h->d_L + (npad + m_rows) * ld, (size_t)npad * sizeof(double),
+                                    hipMemcpyDeviceToDevice, s));
+    h->have_z = true;
+  }
+  return GPX_OK;
+}
+
+static int read_info(gpx_handle* h, int* info) {
+  GPX_HIP_CHECK(h, hipMemcpyAsync(info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->s_main));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  return GPX_OK;
+}
+
+extern "C" int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double* K_out, double* L_out) {
+  if (!h) return GPX_ERR_ARG;
+  GPX_RET(factor_common(h, p, 0, false, K_out));
+  const int64_t n = h->n;
+  if (L_out) {
+    GPX_HIP_CHECK(h, hipMemcpy2DAsync(L_out, (size_t)n * sizeof(double), h->d_L, (size_t)h->ld * sizeof(double),
+                                      (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, h->s_main));
+  }
+  int info = 0;
+  GPX_RET(read_info(h, &info));
+  if (L_out) {  // only the lower triangle of the device buffer is defined
+    for (int64_t i = 0; i < n; ++i)
+      for (int64_t j = i + 1; j < n; ++j) L_out[i * n + j] = 0.0;
+  }
+  return info;
+}
+
+// ------------------------------------------------------- solves against the cached factor
+
+// X L^T = S for `srows` right-hand-side ROWS (S, X: srows x npad, row-major): right-looking,
+//   X_k = S_k W_k^T ;  S_j -= X_k L_jk^T  (j > k)   -- GEMMs only.
+static int solve_rows(gpx_handle* h, double* S, double* X, int64_t srows) {
+  const int64_t nb = h->nb, npad = h->npad, ld = h->ld, nblk = npad / nb;
+  hipStream_t s = h->s_main;
+  for (int64_t k = 0; k < nblk; ++k) {
+    const int64_t c0 = k * nb, r0 = c0 + nb;
+    GemmLaunch g;
+    g.A = S + c0; g.lda = npad;
+    g.B = h->d_W + k * nb * nb; g.ldb = nb;
+    g.C = X + c0; g.ldc = npad;
+    g.M = srows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+    g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+    GPX_RET(launch_gemm_nt(h, s, g));
+    if (r0 >= npad) break;
+    GemmLaunch u;
+    u.A = X + c0; u.lda = npad;
+    u.B = h->d_L + r0 * ld + c0; u.ldb = ld;
+    u.C = S + r0; u.ldc = npad;
+    u.M = srows; u.N = npad - r0; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
+    u.lower = 0; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = srows <= 64 ? 1 : 0;
+    GPX_RET(launch_gemm_nt(h, s, u));
+  }
+  return GPX_OK;
+}
+
+extern "C" int gpx_log_marginal(gpx_handle* h, const double* y_minus_m, double* logp, double* alpha_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (!h->have_factor) { gpx_set_error(h, "gpx_log_marginal: no cached factor (call gpx_fit_factor)"); return GPX_ERR_STATE; }
+  if (!y_minus_m) { gpx_set_error(h, "gpx_log_marginal: y_minus_m is NULL"); return GPX_ERR_ARG; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  const int64_t n = h->n, npad = h->npad, nb = h->nb;
+  hipStream_t s = h->s_main;
+  GPX_RET(ensure(h, &h->d_r, &h->r_cap, n));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  h->have_r = true;
+  // one right-hand-side row, padded to a 64-row GEMM tile
+  const int64_t srows = 64;
+  GPX_RET(ensure(h, &h->d_S, &h->s_cap, 2 * srows * npad));
+  double* S = h->d_S; double* X = h->d_S + srows * npad;
+  GPX_HIP_CHECK(h, hipMemsetAsync(S, 0, (size_t)(srows * npad) * sizeof(double), s));
+  GPX_RET(launch_set_row(h, s, S, h->d_r, n, npad));
+  GPX_RET(solve_rows(h, S, X, srows));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_z, X, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+  h->have_z = true;
+  EpilogueLaunch e;
+  e.L = h->d_L; e.ld = h->ld; e.n = n; e.z = h->d_z; e.vt = nullptr; e.vt_ld = 0; e.m = 0; e.m_new = nullptr;
+  e.prior_diag = 0.0; e.scal = h->d_scal; e.mean = nullptr; e.var = nullptr;
+  GPX_RET(launch_epilogue(h, s, e));
+  if (alpha_out) {
+    // alpha = L^-T z by blocked back-substitution (row form):
+    //   alpha_i^T = (z_i^T - sum_{j>i} alpha_j^T L_ji) W_i
+    GPX_RET(ensure(h, &h->d_vec, &h->vec_cap, 2 * npad));
+    double* t = h->d_vec; double* al = h->d_vec + npad;
+    GPX_HIP_CHECK(h, hipMemcpyAsync(t, h->d_z, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+    for (int64_t k = npad / nb - 1; k >= 0; --k) {
+      const int64_t c0 = k * nb;
+      GPX_RET(launch_gemv_t(h, s, h->d_W + k * nb * nb, nb, (int)nb, nb, t + c0, al + c0, 1.0, 0.0));
+      GPX_RET(launch_gemv_t(h, s, h->d_L + c0 * h->ld, h->ld, (int)nb, c0, al + c0, t, -1.0, 1.0));
+    }
+    GPX_HIP_CHECK(h, hipMemcpyAsync(alpha_out, al, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  double scal[2]; int info = 0;
+  GPX_HIP_CHECK(h, hipMemcpyAsync(scal, h->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPX_RET(read_info(h, &info));
+  if (logp) *logp = -0.5 * scal[1] - scal[0] - 0.5 * (double)n * log(2.0 * M_PI);
+  return info;
+}
+
+static void cached_params(gpx_handle* h, gpx_kernel_params* q) {
+  memset(q, 0, sizeof(*q));
+  q->kind = h->f_kind; q->k_scale = h->f_scale; q->k_jitter = h->f_jitter;
+  q->k_length = h->f_length.data(); q->n_length = (int)h->f_length.size();
+  q->k_period = h->f_period.empty() ? nullptr : h->f_period.data(); q->n_period = (int)h->f_period.size();
+  q->k_noise = nullptr; q->n_noise = 0; q->apply_noise = 0;
+}
+
+extern "C" int gpx_posterior(gpx_handle* h, const double* m_new, double new_noise, double* mean_out,
+                             double* var_out, double* cov_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (!h->have_factor || !h->have_z) {
+    gpx_set_error(h, "gpx_posterior: needs gpx_fit_factor + gpx_log_marginal (or gpx_fit_predict) first");
+    return GPX_ERR_STATE;
+  }
+  const int64_t m = h->m;
+  if (m <= 0) return GPX_OK;  // empty x_new: nothing to write
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  const int64_t n = h->n, npad = h->npad; const int d = h->d;
+  hipStream_t s = h->s_main;
+  const int64_t mpad = round_up(m, 64);
+  GPX_RET(ensure(h, &h->d_S, &h->s_cap, 2 * mpad * npad));
+  double* S = h->d_S; double* X = h->d_S + mpad * npad;
+  gpx_kernel_params q; cached_params(h, &q);
+  const double* noise_dev; double noise_scalar;
+  GPX_RET(upload_params(h, s, &q, m, d, &noise_dev, &noise_scalar));
+  if (mpad != m || npad != n) GPX_HIP_CHECK(h, hipMemsetAsync(S, 0, (size_t)(mpad * npad) * sizeof(double), s));
+  GramLaunch g;
+  g.kind = q.kind; g.d = d; g.k_scale = q.k_scale; g.hyp = h->d_hyp;
+  g.x1 = h->d_xnew; g.x2 = h->d_x; g.n1 = m; g.n2 = n; g.out = S; g.ld = npad;
+  g.lower_only = 0; g.diag_rule = 0; g.noise = nullptr; g.noise_scalar = 0.0; g.jitter = 0.0;
+  GPX_RET(launch_gram(h, s, g));  // k_cross = f(x_new, x, apply_noise=False)  gpax/gp.py:282
+  GPX_RET(solve_rows(h, S, X, mpad));
+  GPX_RET(ensure(h, &h->d_mean, &h->out_cap, 2 * m));
+  h->d_var = h->d_mean + m;
+  const double* mnew_dev = nullptr;
+  if (m_new) {
+    GPX_RET(ensure(h, &h->d_mnew, &h->mnew_cap, m));
+    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_mnew, m_new, (size_t)m * sizeof(double), hipMemcpyHostToDevice, s));
+    mnew_dev = h->d_mnew;
+  }
+  EpilogueLaunch e;
+  e.L = h->d_L; e.ld = h->ld; e.n = n; e.z = h->d_z; e.vt = X; e.vt_ld = npad; e.m = m; e.m_new = mnew_dev;
+  e.prior_diag = kernel_diag_value(q.kind, q.k_scale) + (new_noise + q.k_jitter);  // diagonal of k_new, gp.py:287
+  e.scal = h->d_scal + 2; e.mean = h->d_mean; e.var = h->d_var;
+  GPX_RET(launch_epilogue(h, s, e));
+  if (mean_out) GPX_HIP_CHECK(h, hipMemcpyAsync(mean_out, h->d_mean, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (var_out) GPX_HIP_CHECK(h, hipMemcpyAsync(var_out, h->d_var, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (cov_out) {
+    // cov = k_new - V^T V  (gpax/gp.py:298-299 with A = K^-1 k_cross^T = L^-T V)
+    GPX_RET(ensure(h, &h->d_cov, &h->cov_cap, mpad * mpad));
+    GramLaunch c = g;
+    c.x2 = h->d_xnew; c.n2 = m; c.out = h->d_cov; c.ld = mpad; c.diag_rule = 1; c.noise_scalar = new_noise;
+    c.jitter = q.k_jitter;
+    GPX_RET(launch_gram(h, s, c));
+    GemmLaunch u;
+    u.A = X; u.lda = npad; u.B = X; u.ldb = npad; u.C = h->d_cov; u.ldc = mpad;
+    u.M = mpad; u.N = mpad; u.K = npad; u.alpha = -1.0; u.beta = 1.0;
+    u.lower = 0; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = mpad <= 256 ? 1 : 0;
+    GPX_RET(launch_gemm_nt(h, s, u));
+    GPX_HIP_CHECK(h, hipMemcpy2DAsync(cov_out, (size_t)m * sizeof(double), h->d_cov, (size_t)mpad * sizeof(double),
+                                      (size_t)m * sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
+  }
+  int info = 0;
+  GPX_RET(read_info(h, &info));
+  return info;
+}
+
+extern "C" int gpx_prior_cov(gpx_handle* h, const gpx_kernel_params* p, double new_noise, double* cov_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (!cov_out || !p) { gpx_set_error(h, "gpx_prior_cov: bad argument"); return GPX_ERR_ARG; }
+  const int64_t m = h->m;
+  if (m <= 0 || !h->d_xnew) { gpx_set_error(h, "gpx_prior_cov: call gpx_set_test first"); return GPX_ERR_STATE; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  hipStream_t s = h->s_main;
+  gpx_kernel_params q = *p; q.n_noise = 0; q.k_noise = nullptr;
+  const double* noise_dev; double noise_scalar;
+  GPX_RET(upload_params(h, s, &q, m, h->d, &noise_dev, &noise_scalar));
+  GPX_RET(ensure(h, &h->d_cov, &h->cov_cap, m * m));
+  GramLaunch g;
+  g.kind = q.kind; g.d = h->d; g.k_scale = q.k_scale; g.hyp = h->d_hyp;
+  g.x1 = h->d_xnew; g.x2 = h->d_xnew; g.n1 = m; g.n2 = m; g.out = h->d_cov; g.ld = m;
+  g.lower_only = 0; g.diag_rule = 1; g.noise = nullptr; g.noise_scalar = new_noise; g.jitter = q.k_jitter;
+  GPX_RET(launch_gram(h, s, g));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(cov_out, h->d_cov, (size_t)(m * m) * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(s));
+  return GPX_OK;
+}
+
+// ------------------------------------------------------------------ fused fit+predict
+
+extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, double new_noise) {
+  if (!h) return GPX_ERR_ARG;
+  if (!h->have_r) { gpx_set_error(h, "gpx_fit_predict_async: call gpx_set_targets first"); return GPX_ERR_STATE; }
+  const int64_t m = h->m;
+  hipStream_t s = h->s_main;
+  prof_begin(h, s, GPX_STAGE_FACTOR_TOTAL, 0.0, 0.0);
+  GPX_RET(factor_common(h, p, m, true, nullptr));
+  GPX_RET(ensure(h, &h->d_mean, &h->out_cap, 2 * std::max<int64_t>(m, 1)));
+  h->d_var = h->d_mean + std::max<int64_t>(m, 1);
+  EpilogueLaunch e;
+  e.L = h->d_L; e.ld = h->ld; e.n = h->n; e.z = h->d_L + (h->npad + m) * h->ld;
+  e.vt = h->d_L + h->npad * h->ld; e.vt_ld = h->ld; e.m = m;
+  e.m_new = h->have_mnew ? h->d_mnew : nullptr;
+  e.prior_diag = kernel_diag_value(p->kind, p->k_scale) + (new_noise + p->k_jitter);
+  e.scal = h->d_scal; e.mean = h->d_mean; e.var = h->d_var;
+  prof_begin(h, s, GPX_STAGE_EPILOGUE, 4.0 * (m + 1.0) * h->n, 8.0 * (m + 2.0) * h->n);
+  GPX_RET(launch_epilogue(h, s, e));
+  prof_end(h, s);
+  if (h->prof_mode) {  // close the FACTOR_TOTAL bracket (first pending of this call)
+    for (size_t i = h->pending.size(); i-- > 0;)
+      if (h->pending[i].stage == GPX_STAGE_FACTOR_TOTAL) { (void)hipEventRecord(h->pending[i].b, s); break; }
+  }
+  return GPX_OK;
+}
+
+extern "C" int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, double* var_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (!h->have_factor || !h->r_in_factor) { gpx_set_error(h, "gpx_fetch_results: no fit_predict results"); return GPX_ERR_STATE; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  hipStream_t s = h->s_main;
+  const int64_t m = h->m_in_factor;
+  double scal[2]; int info = 0;
+  GPX_HIP_CHECK(h, hipMemcpyAsync(scal, h->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (mean_out && m > 0) GPX_HIP_CHECK(h, hipMemcpyAsync(mean_out, h->d_mean, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (var_out && m > 0) GPX_HIP_CHECK(h, hipMemcpyAsync(var_out, h->d_var, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPX_RET(read_info(h, &info));
+  if (logp) *logp = -0.5 * scal[1] - scal[0] - 0.5 * (double)h->n * log(2.0 * M_PI);
+  return info;
+}
+
+extern "C" int gpx_fit_predict(gpx_handle* h, const gpx_kernel_params* p, const double* y_minus_m,
+                               const double* m_new, double new_noise, double* logp, double* mean_out,
+                               double* var_out) {
+  if (!h) return GPX_ERR_ARG;
+  GPX_RET(gpx_set_targets(h, y_minus_m, m_new));
+  GPX_RET(gpx_fit_predict_async(h, p, new_noise));
+  return gpx_fetch_results(h, logp, mean_out, var_out);
+}
+
+// ------------------------------------------------------------------- measurement API
+
+extern "C" int gpx_profile_mode(gpx_handle* h, int mode) {
+  if (!h) return GPX_ERR_ARG;
+  GPX_RET(prof_collect(h));
+  h->prof_mode = mode;
+  return GPX_OK;
+}
+
+extern "C" int gpx_profile_reset(gpx_handle* h) {
+  if (!h) return GPX_ERR_ARG;
+  GPX_RET(prof_collect(h));
+  for (auto& p : h->prof) p = StageProf();
+  return GPX_OK;
+}
+
+extern "C" int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launches, double* flops,
+                               double* bytes) {
+  if (!h || stage < 0 || stage >= GPX_N_STAGES) return GPX_ERR_ARG;
+  GPX_RET(prof_collect(h));
+  if (total_ms) *total_ms = h->prof[stage].ms;
+  if (launches) *launches = h->prof[stage].launches;
+  if (flops) *flops = h->prof[stage].flops;
+  if (bytes) *bytes = h->prof[stage].bytes;
+  return GPX_OK;
+}

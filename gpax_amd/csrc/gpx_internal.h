@@ -1,0 +1,166 @@
+// gpx_internal.h -- shared declarations of the HIP implementation (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/gpx.h"
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------ error plumbing
+#define GPX_HIP_CHECK(h, expr)                                                         \
+  do {                                                                                 \
+    hipError_t e__ = (expr);                                                           \
+    if (e__ != hipSuccess) {                                                           \
+      gpx_set_error(h, std::string(#expr) + ": " + hipGetErrorString(e__));            \
+      return GPX_ERR_HIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+#define GPX_RET(expr)                \
+  do {                               \
+    int r__ = (expr);                \
+    if (r__ != GPX_OK) return r__;   \
+  } while (0)
+
+void gpx_set_error(gpx_handle* h, const std::string& msg);
+
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// --------------------------------------------------------------------- device hyper
+// Hyper-parameters as the gram kernel consumes them: per-dimension length-scale and
+// period expanded to d entries (device buffer, 2*d doubles: length[d], period[d]).
+struct GramLaunch {
+  int kind;
+  int d;
+  double k_scale;
+  const double* hyp;    // device: length[d] then period[d]
+  const double* x1;     // device (n1,d)
+  const double* x2;     // device (n2,d)
+  int64_t n1, n2;
+  double* out;          // device, leading dimension ld
+  int64_t ld;
+  int lower_only;       // skip tiles strictly above the diagonal (x1 == x2 layouts)
+  int diag_rule;        // add noise+jitter on the diagonal
+  const double* noise;  // device vector (n1) or NULL
+  double noise_scalar;  // used when noise == NULL
+  double jitter;
+};
+int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& g);
+
+// C[M,N] = beta*C + alpha * A[M,K] * B[N,K]^T   (all row-major; K contiguous in A and B)
+struct GemmLaunch {
+  const double* A; int64_t lda;
+  const double* B; int64_t ldb;
+  double* C; int64_t ldc;
+  int64_t M, N, K;
+  double alpha, beta;
+  int lower;            // only tiles that intersect {row_off + i >= col_off + j}
+  int64_t row_off, col_off;
+  int b_lower_tri;      // B is lower triangular (B[n][k] = 0 for k > n): skip dead K
+  int small_tile;       // 1: 32x32 workgroup tiles (latency path), 0: 64x64 (throughput path)
+};
+int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
+
+// Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
+int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda,
+                      double* L, int64_t ldl, double* W, int* info, int col0);
+
+// y[0:ncols) = beta*y + alpha * x[0:nrows)^T A[0:nrows, 0:ncols)
+int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, int nrows, int64_t ncols,
+                  const double* x, double* y, double alpha, double beta);
+
+// fill helpers
+int launch_fill_rect(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t r0, int64_t r1,
+                     int64_t c0, int64_t c1, double diag);
+int launch_fill_identity_pad(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t n,
+                             int64_t npad, int64_t rows_total);
+int launch_set_row(gpx_handle* h, hipStream_t s, double* dst, const double* src, int64_t n,
+                   int64_t npad);
+
+// epilogue reductions
+struct EpilogueLaunch {
+  const double* L; int64_t ld;   // factor (diagonal is read for the log-determinant)
+  int64_t n;                     // valid order
+  const double* z;               // device (n): z = L^-1 (y - m), or NULL (then only logdet)
+  const double* vt; int64_t vt_ld;  // V^T = k_cross L^-T, m rows
+  int64_t m;                     // test rows
+  const double* m_new;           // device (m) or NULL
+  double prior_diag;             // k(x*,x*) incl. noise+jitter of the diagonal rule
+  double* scal;                  // device: [0]=logdet [1]=quad
+  double* mean; double* var;     // device (m)
+};
+int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
+
+// ------------------------------------------------------------------------ the handle
+struct StageProf {
+  double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0;
+};
+
+struct gpx_handle {
+  int device = 0;
+  hipStream_t s_main = nullptr, s_trail = nullptr;
+  std::string err;
+  hipDeviceProp_t prop;
+
+  // options
+  int nb = 128;
+  int lookahead = 1;
+  int use_graph = 0;
+
+  // resident inputs
+  double* d_x = nullptr; int64_t n = 0; int d = 0; int64_t x_cap = 0;
+  double* d_xnew = nullptr; int64_t m = 0; int64_t xnew_cap = 0;
+  double* d_r = nullptr; int64_t r_cap = 0; bool have_r = false;
+  double* d_mnew = nullptr; int64_t mnew_cap = 0; bool have_mnew = false;
+  double* d_hyp = nullptr; int64_t hyp_cap = 0;
+  double* d_noise = nullptr; int64_t noise_cap = 0;
+
+  // factor workspace: A (working copy, lower) and L (result) share a layout:
+  // rows [0,npad) the matrix, rows [npad, npad+epad) the border rows (k_cross, then r)
+  double* d_A = nullptr; double* d_L = nullptr; int64_t a_cap = 0, l_cap = 0;
+  double* d_W = nullptr; int64_t w_cap = 0;     // (npad/nb) blocks of nb*nb: inv(L_kk)
+  int64_t npad = 0, epad = 0, ld = 0;
+  int64_t m_in_factor = 0; bool r_in_factor = false;
+  bool have_factor = false;
+
+  // cached hyper-parameters of the factor (for later posterior calls)
+  int f_kind = 0; double f_scale = 0, f_jitter = 0;
+  std::vector<double> f_length, f_period;
+
+  // solve workspace for posterior-with-cached-factor
+  double* d_S = nullptr; int64_t s_cap = 0;      // rows x npad
+  double* d_cov = nullptr; int64_t cov_cap = 0;
+  double* d_z = nullptr; int64_t z_cap = 0; bool have_z = false;  // z = L^-1 r (npad)
+
+  // scratch of the stateless gpx_gram and of the vector back-substitution
+  double* d_g1 = nullptr; int64_t g1_cap = 0;
+  double* d_g2 = nullptr; int64_t g2_cap = 0;
+  double* d_gout = nullptr; int64_t gout_cap = 0;
+  double* d_vec = nullptr; int64_t vec_cap = 0;
+
+  // small outputs
+  double* d_scal = nullptr;    // [0]=logdet [1]=quad
+  int* d_info = nullptr;
+  double* d_mean = nullptr; double* d_var = nullptr; int64_t out_cap = 0;  // d_var aliases d_mean + m
+  double* h_pinned = nullptr; int64_t pinned_cap = 0;  // pinned staging for small results
+
+  // events for the two-stream lookahead
+  std::vector<hipEvent_t> ev_panel, ev_trail;
+
+  // profiling
+  int prof_mode = 0;
+  StageProf prof[GPX_N_STAGES];
+  struct PendingEv { int stage; hipEvent_t a, b; };
+  std::vector<PendingEv> pending;
+  std::vector<hipEvent_t> ev_pool;
+};
+
+// profiling helpers (api.hip)
+void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double bytes);
+void prof_end(gpx_handle* h, hipStream_t s);

@@ -1,0 +1,202 @@
+// gram.hip -- tiled pairwise-distance / gram-matrix builder for gfx950.
+//
+// Replaces, in one fused kernel, the JAX-primitive sequence of
+//   _squared_distance            gpax/kernels.py:39-51
+//   RBFKernel._kernel_function   gpax/kernels.py:112-126
+//   MaternKernel (nu=5/2)        gpax/kernels.py:131-147   (r = sqrt(r2 + 1e-12))
+//   PeriodicKernel               gpax/kernels.py:152-168   (direct differences, sin)
+// including the diagonal rule `(k_noise + k_jitter) * eye(n)`.
+//
+// HBM-bound: the output is written exactly once (8 B/entry, 16 B per lane per store,
+// two full 512-B row segments per wave-instruction) and each 64-row X block is read
+// once per tile into LDS (coalesced 32-B pieces), so HBM traffic is the algorithmic
+// 8*n1*n2 + 8*(n1+n2)*d bytes (the X re-reads per tile are L2 hits).
+// Distances use direct differences (sum_k (a_k-b_k)^2): free of the cancellation of
+// the |a|^2-2ab+|b|^2 expansion, never negative (so no clip needed), and within
+// 1e-15 of the reference's expansion form (tests/test_oracle.py).
+// fp64 MFMA is NOT used here on purpose: on gfx950 v_mfma_f64 runs at the vector
+// fp64 rate, the inner dimension d is tiny, and the kernel is bound by HBM writes
+// and the fp64 exp, not by the distance arithmetic.
+
+#include "gpx_internal.h"
+
+#define GT 64   // output tile edge (64 x 64 entries per 256-thread workgroup)
+#define DC 16   // input-dimension chunk staged in LDS per pass
+
+struct GramArgs {
+  const double* x1; const double* x2;
+  const double* hyp;     // length[d], period[d]
+  const double* noise;   // per-row noise or nullptr
+  double* out;
+  int64_t n1, n2, ld;
+  int d;
+  int lower_only, diag_rule;
+  double k_scale, noise_scalar, jitter;
+};
+
+template <int KIND, bool VEC2>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
+  // X1 block row-major [row][k] (read as wave-uniform broadcasts), X2 block
+  // transposed [k][col] (read as 16-B pairs by consecutive lanes: conflict-free).
+  __shared__ double x1s[GT][DC];
+  __shared__ __attribute__((aligned(16))) double x2s[DC][GT];
+  __shared__ double len_s[DC], per_s[DC];
+
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
+  if (g.lower_only && j0 > i0 + GT - 1) return;
+
+  const int cj = tid & 31;   // column pair: cols 2cj, 2cj+1
+  const int ri = tid >> 5;   // row group: rows 8ri .. 8ri+7
+  double acc[8][2];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r][0] = acc[r][1] = 0.0;
+
+  const int lrow = tid >> 2;        // staging: 4 threads per row, 4 doubles each
+  const int lk = (tid & 3) * 4;
+
+  for (int dc0 = 0; dc0 < g.d; dc0 += DC) {
+    if (tid < DC) {
+      int k = dc0 + tid;
+      len_s[tid] = k < g.d ? g.hyp[k] : 1.0;
+      per_s[tid] = k < g.d ? g.hyp[g.d + k] : 1.0;
+    }
+    // stage (scaled for RBF/Matern: x / lengthscale as gpax/kernels.py:45-46; raw for periodic)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = dc0 + lk + q;
+      double a = 0.0, b = 0.0;
+      if (k < g.d) {
+        const double len = g.hyp[k];
+        if (i0 + lrow < g.n1) a = g.x1[(i0 + lrow) * g.d + k];
+        if (j0 + lrow < g.n2) b = g.x2[(j0 + lrow) * g.d + k];
+        if (KIND != GPX_PERIODIC) { a = a / len; b = b / len; }
+      }
+      x1s[lrow][lk + q] = a;
+      x2s[lk + q][lrow] = b;
+    }
+    __syncthreads();
+    const int kmax = (g.d - dc0) < DC ? (g.d - dc0) : DC;
+    for (int k = 0; k < kmax; ++k) {
+      const v2d b = *reinterpret_cast<const v2d*>(&x2s[k][2 * cj]);
+      double pk = 0.0, lk_ = 0.0;
+      if (KIND == GPX_PERIODIC) { pk = per_s[k]; lk_ = len_s[k]; }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const double a = x1s[ri * 8 + r][k];
+        double d0 = a - b.x, d1 = a - b.y;
+        if (KIND == GPX_PERIODIC) {
+          // sin(pi * d / k_period) / k_length   (gpax/kernels.py:164)
+          d0 = sin(M_PI * d0 / pk) / lk_;
+          d1 = sin(M_PI * d1 / pk) / lk_;
+        }
+        acc[r][0] = fma(d0, d0, acc[r][0]);
+        acc[r][1] = fma(d1, d1, acc[r][1]);
+      }
+    }
+    __syncthreads();
+  }
+
+  const int64_t col = j0 + 2 * cj;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int64_t row = i0 + ri * 8 + r;
+    if (row >= g.n1) continue;
+    double kv[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const double r2 = acc[r][c];
+      double k;
+      if (KIND == GPX_RBF) {
+        k = g.k_scale * exp(-0.5 * r2);                       // kernels.py:123
+      } else if (KIND == GPX_MATERN52) {
+        const double rr = sqrt(r2 + 1e-12);                   // kernels.py:142
+        const double s5r = 2.2360679774997896964 * rr;             // 5**0.5 * r
+        k = g.k_scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);  // kernels.py:144
+      } else {
+        k = g.k_scale * exp(-2.0 * r2);                       // kernels.py:165
+      }
+      if (g.diag_rule && row == col + c) {
+        const double nz = g.noise ? g.noise[row] : g.noise_scalar;
+        k += (nz + g.jitter);                                 // kernels.py:124-125
+      }
+      kv[c] = k;
+    }
+    double* dst = g.out + row * g.ld + col;
+    if (VEC2 && col + 1 < g.n2) {
+      v2d v; v.x = kv[0]; v.y = kv[1];
+      *reinterpret_cast<v2d*>(dst) = v;
+    } else {
+      if (col < g.n2) dst[0] = kv[0];
+      if (col + 1 < g.n2) dst[1] = kv[1];
+    }
+  }
+}
+
+int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
+  if (L.n1 <= 0 || L.n2 <= 0) return GPX_OK;
+  GramArgs g;
+  g.x1 = L.x1; g.x2 = L.x2; g.hyp = L.hyp; g.noise = L.noise; g.out = L.out;
+  g.n1 = L.n1; g.n2 = L.n2; g.ld = L.ld; g.d = L.d;
+  g.lower_only = L.lower_only; g.diag_rule = L.diag_rule;
+  g.k_scale = L.k_scale; g.noise_scalar = L.noise_scalar; g.jitter = L.jitter;
+  dim3 grid((unsigned)((L.n2 + GT - 1) / GT), (unsigned)((L.n1 + GT - 1) / GT));
+  const bool vec2 = (L.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(L.out) & 15) == 0);
+#define GPX_GRAM_LAUNCH(KIND)                                                        \
+  do {                                                                               \
+    if (vec2) hipLaunchKernelGGL((gram_kernel<KIND, true>), grid, dim3(256), 0, s, g);  \
+    else hipLaunchKernelGGL((gram_kernel<KIND, false>), grid, dim3(256), 0, s, g);      \
+  } while (0)
+  switch (L.kind) {
+    case GPX_RBF: GPX_GRAM_LAUNCH(GPX_RBF); break;
+    case GPX_MATERN52: GPX_GRAM_LAUNCH(GPX_MATERN52); break;
+    case GPX_PERIODIC: GPX_GRAM_LAUNCH(GPX_PERIODIC); break;
+    default: gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
+  }
+#undef GPX_GRAM_LAUNCH
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
+// ------------------------------------------------------------------- fill helpers
+
+// out[r][c] = (r == c) ? diag : 0   for r in [r0,r1), c in [c0,c1)
+__global__ void fill_rect_kernel(double* A, int64_t ld, int64_t r0, int64_t r1, int64_t c0,
+                                 int64_t c1, double diag) {
+  const int64_t c = c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = r0 + blockIdx.y;
+  if (c < c1 && r < r1) A[r * ld + c] = (r == c) ? diag : 0.0;
+}
+
+int launch_fill_rect(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t r0, int64_t r1,
+                     int64_t c0, int64_t c1, double diag) {
+  if (r1 <= r0 || c1 <= c0) return GPX_OK;
+  dim3 grid((unsigned)((c1 - c0 + 255) / 256), (unsigned)(r1 - r0));
+  hipLaunchKernelGGL(fill_rect_kernel, grid, dim3(256), 0, s, A, ld, r0, r1, c0, c1, diag);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
+// Padding of the (npad x npad) matrix to identity outside the valid (n x n) part:
+// chol([[K,0],[0,I]]) = [[L,0],[0,I]] exactly, so padding never perturbs L.
+int launch_fill_identity_pad(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t n,
+                             int64_t npad, int64_t rows_total) {
+  GPX_RET(launch_fill_rect(h, s, A, ld, 0, rows_total, n, npad, 1.0));  // columns [n,npad) of every row
+  GPX_RET(launch_fill_rect(h, s, A, ld, n, npad, 0, n, 1.0));           // rows [n,npad), columns [0,n)
+  return GPX_OK;
+}
+
+// dst[0:n) = src[0:n) (or 0 when src == nullptr), dst[n:npad) = 0
+__global__ void set_row_kernel(double* dst, const double* src, int64_t n, int64_t npad) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < npad) dst[c] = (src && c < n) ? src[c] : 0.0;
+}
+
+int launch_set_row(gpx_handle* h, hipStream_t s, double* dst, const double* src, int64_t n,
+                   int64_t npad) {
+  if (npad <= 0) return GPX_OK;
+  hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, dst, src,
+                     n, npad);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}

@@ -1,0 +1,96 @@
+// reduce.hip -- epilogue reductions and the vector back-substitution helper (gfx950).
+//
+//   log-marginal pieces   sum_i log L_ii  and  |z|^2, z = L^-1 (y - m)   (numpyro MVN.log_prob
+//                         reached from gpax/gp.py:147-151)
+//   posterior             mean = m_new + V^T z,  var = k(x*,x*) - |V_m|^2   with V^T = k_cross L^-T
+//                         (gpax/gp.py:297-301 in the V-form; only diag(cov) is used by
+//                         _fast_predict, gpax/gp.py:484)
+// All HBM-bound row reductions: each row is read once, contiguously.
+
+#include "gpx_internal.h"
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// deterministic block-wide sums of two values; result valid in thread 0
+template <int NT>
+__device__ __forceinline__ void block_sum2(double& a, double& b) {
+  __shared__ double sa[NT / 64], sb[NT / 64];
+  a = wave_sum(a);
+  b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) { sa[wave] = a; sb[wave] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double ta = 0.0, tb = 0.0;
+    for (int w = 0; w < NT / 64; ++w) { ta += sa[w]; tb += sb[w]; }
+    a = ta; b = tb;
+  }
+}
+
+__global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* L, int64_t ld, int64_t n,
+                                                         const double* z, double* scal) {
+  double s1 = 0.0, s2 = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    s1 += log(L[i * ld + i]);
+    if (z) { const double v = z[i]; s2 = fma(v, v, s2); }
+  }
+  block_sum2<1024>(s1, s2);
+  if (threadIdx.x == 0) { scal[0] = s1; scal[1] = s2; }
+}
+
+__global__ __launch_bounds__(256) void post_reduce_kernel(const double* vt, int64_t ld, int64_t n,
+                                                         const double* z, const double* m_new,
+                                                         double prior_diag, double* mean, double* var) {
+  const int64_t row = blockIdx.x;
+  const double* v = vt + row * ld;
+  double dot = 0.0, ss = 0.0;
+  for (int64_t c = threadIdx.x; c < n; c += 256) {
+    const double x = v[c];
+    dot = fma(x, z[c], dot);
+    ss = fma(x, x, ss);
+  }
+  block_sum2<256>(dot, ss);
+  if (threadIdx.x == 0) {
+    mean[row] = (m_new ? m_new[row] : 0.0) + dot;
+    var[row] = prior_diag - ss;
+  }
+}
+
+int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
+  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, s, e.L, e.ld, e.n, e.z, e.scal);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  if (e.m > 0 && e.z) {
+    hipLaunchKernelGGL(post_reduce_kernel, dim3((unsigned)e.m), dim3(256), 0, s, e.vt, e.vt_ld, e.n, e.z,
+                       e.m_new, e.prior_diag, e.mean, e.var);
+    GPX_HIP_CHECK(h, hipGetLastError());
+  }
+  return GPX_OK;
+}
+
+// y[0:ncols) = beta*y + alpha * sum_{r<nrows} x[r] * A[r][0:ncols)    (A row-major: coalesced along c)
+__global__ __launch_bounds__(256) void gemv_t_kernel(const double* A, int64_t lda, int nrows,
+                                                    int64_t ncols, const double* x, double* y,
+                                                    double alpha, double beta) {
+  __shared__ double xs[256];
+  if (threadIdx.x < nrows) xs[threadIdx.x] = x[threadIdx.x];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncols) return;
+  double acc = 0.0;
+  for (int r = 0; r < nrows; ++r) acc = fma(xs[r], A[(int64_t)r * lda + c], acc);
+  y[c] = (beta != 0.0 ? beta * y[c] : 0.0) + alpha * acc;
+}
+
+int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, int nrows, int64_t ncols,
+                  const double* x, double* y, double alpha, double beta) {
+  if (ncols <= 0) return GPX_OK;
+  if (nrows > 256) { gpx_set_error(h, "gemv_t: nrows > 256"); return GPX_ERR_ARG; }
+  hipLaunchKernelGGL(gemv_t_kernel, dim3((unsigned)((ncols + 255) / 256)), dim3(256), 0, s, A, lda, nrows,
+                     ncols, x, y, alpha, beta);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}

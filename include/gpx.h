@@ -1,0 +1,158 @@
+/* gpx.h -- C ABI of the MI355X-native exact-GP core (libgpx_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of matthewcarbone/gpax: gram build ->
+ * Cholesky -> log-marginal likelihood -> predictive posterior, all fp64.
+ * The reference has no FFI of its own (pure Python over JAX/NumPyro); each entry
+ * point below names the reference interface it replaces (file:line relative to
+ * the reference checkout).  INTEGRATION.md shows the ctypes binding a gpax
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types;
+ *   - every array is row-major contiguous `double`; HOST pointers, owned by the
+ *     caller and never retained past the call (device copies live in the handle);
+ *   - every function returns an int status: 0 = ok, > 0 = LAPACK-style `info`
+ *     (1-based index of the first non-positive pivot; outputs are NaN-filled from
+ *     there on, mirroring JAX's silent-NaN Cholesky), < 0 = GPX_ERR_*;
+ *   - one caller thread per handle (not re-entrant); ctypes drops the GIL.
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_ABI_VERSION 1
+
+/* kernel kinds: gpax/kernels.py:110 (RBFKernel), :129 (MaternKernel nu=5/2), :150 (PeriodicKernel) */
+#define GPX_RBF 0
+#define GPX_MATERN52 1
+#define GPX_PERIODIC 2
+
+#define GPX_OK 0
+#define GPX_ERR_ARG (-1)         /* bad argument / shape */
+#define GPX_ERR_HIP (-2)         /* HIP runtime error (see gpx_last_error) */
+#define GPX_ERR_STATE (-3)       /* call order: e.g. posterior before fit */
+#define GPX_ERR_NOMEM (-4)
+#define GPX_ERR_COMM (-5)        /* RCCL error */
+#define GPX_ERR_UNSUPPORTED (-6)
+
+typedef struct gpx_handle gpx_handle;
+
+/* The keyword set of Kernel.__call__ / _kernel_function
+ * (gpax/kernels.py:112-121 RBF, :131-140 Matern, :152-162 periodic).
+ * Hyper-parameters arrive from gpax with shape (1,) or (plate,):
+ *   k_length: n_length = 1 (isotropic) or d (ARD, gpax/kernels.py:45-46 broadcast)
+ *   k_period: n_period = 0 (not periodic), 1 or d
+ *   k_noise : n_noise  = 0 (noise = 0.0), 1 (scalar k_noise) or n1 (vector, the
+ *             y_std**2 of gpax/gp.py:289-293)
+ * The diagonal rule `(k_noise + k_jitter) * eye(n)` is applied iff
+ * apply_noise != 0 AND n1 == n2 (gpax/kernels.py:124: keyed on shapes). */
+typedef struct gpx_kernel_params {
+  int32_t kind;
+  int32_t n_length;
+  int32_t n_period;
+  int32_t n_noise;
+  int32_t apply_noise;
+  int32_t reserved;
+  double k_scale;
+  double k_jitter;
+  const double* k_length;
+  const double* k_period;
+  const double* k_noise;
+} gpx_kernel_params;
+
+int gpx_abi_version(void);
+
+/* Replaces gpax.state.set_device (gpax/state.py:61-70): bind a handle to one GPU.
+ * The handle owns its HIP streams, workspaces and the cached factor. */
+int gpx_create(int device_id, gpx_handle** out);
+int gpx_destroy(gpx_handle* h);
+/* Text of the last error on this handle (h may be NULL: last create error). */
+const char* gpx_last_error(const gpx_handle* h);
+int gpx_device_name(gpx_handle* h, char* buf, int len);
+int gpx_synchronize(gpx_handle* h);
+
+/* Kernel.__call__(x1, x2, **params) -> (n1, n2)  (gpax/kernels.py:93-94 and the
+ * three _kernel_function bodies).  x1 (n1,d), x2 (n2,d), out (n1,n2). */
+int gpx_gram(gpx_handle* h, const gpx_kernel_params* p, const double* x1, int64_t n1,
+             const double* x2, int64_t n2, int32_t d, double* out);
+
+/* jax.device_put(x, state.device) of gpax/gp.py:527 / :396: make the (already
+ * transformed) training inputs x (n,d) / test inputs x_new (m,d) resident in HBM. */
+int gpx_set_train(gpx_handle* h, const double* x, int64_t n, int32_t d);
+int gpx_set_test(gpx_handle* h, const double* x_new, int64_t m);
+
+/* k_train = f(x, x, k_noise, k_jitter) + cho_factor  (gpax/gp.py:293,296; the same
+ * factor is the one inside dist.MultivariateNormal at gpax/gp.py:147-151).
+ * Builds K on the device, factorises K = L L^T (lower) and caches L.
+ * K_out / L_out: optional (may be NULL) host copies, (n,n) each; L_out has zeros
+ * above the diagonal. */
+int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double* K_out, double* L_out);
+
+/* log-density of MultivariateNormal(loc=m, covariance_matrix=k) at y
+ * (gpax/gp.py:145-151, `obs=y`): uses the cached L.  y_minus_m (n,) = y - mean(x).
+ * logp = -0.5*|L^-1 r|^2 - sum(log diag L) - n/2*log(2 pi).
+ * alpha_out: optional (n,) = K^-1 r  (the `B` of gpax/gp.py:300). */
+int gpx_log_marginal(gpx_handle* h, const double* y_minus_m, double* logp, double* alpha_out);
+
+/* _get_mean_and_covariance (gpax/gp.py:247-312, Cholesky branch :295-301) at the
+ * resident x_new with the cached factor and the y_minus_m of the last
+ * gpx_log_marginal:  mean = m_new + k_cross K^-1 r,  cov = k_new - k_cross K^-1 k_cross^T,
+ * where k_new = f(x_new, x_new, k_noise=new_noise, k_jitter) (gpax/gp.py:283-287:
+ * new_noise = k_noise if observation_noise else 0).
+ * m_new (m,) may be NULL (= 0).  Outputs (each optional): mean_out (m,),
+ * var_out (m,) = diag(cov)  [what _fast_predict uses, gpax/gp.py:484], cov_out (m,m). */
+int gpx_posterior(gpx_handle* h, const double* m_new, double new_noise, double* mean_out,
+                  double* var_out, double* cov_out);
+
+/* _get_mean_and_covariance_unconditioned's covariance (gpax/gp.py:212-245):
+ * cov = f(x_new, x_new, k_noise=new_noise, k_jitter) at the resident x_new. */
+int gpx_prior_cov(gpx_handle* h, const gpx_kernel_params* p, double new_noise, double* cov_out);
+
+/* One whole fit+predict step at one hyper-parameter setting -- the unit of the
+ * benchmark metric and of _fast_predict (gpax/gp.py:464-484):
+ * gram(x,x) + Cholesky + log-marginal + gram(x_new,x) + posterior mean/variance,
+ * run as ONE bordered factorisation (k_cross and r ride along as extra rows, so
+ * the triangular solves are absorbed into the panel updates).  Also caches L.
+ * Requires gpx_set_train; uses the resident x_new if gpx_set_test was called (m may be 0).
+ * Any of logp / mean_out / var_out may be NULL. */
+int gpx_fit_predict(gpx_handle* h, const gpx_kernel_params* p, const double* y_minus_m,
+                    const double* m_new, double new_noise, double* logp, double* mean_out,
+                    double* var_out);
+
+/* Same work as gpx_fit_predict but only ENQUEUED on the handle's streams: inputs must
+ * already be resident (gpx_set_train/gpx_set_test/gpx_set_targets), results stay in HBM
+ * until gpx_fetch_results.  This is what bench.py times (inputs resident in HBM). */
+int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const double* m_new);
+int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, double new_noise);
+int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, double* var_out);
+
+/* ---- measurement hooks (bench.py; HIP events on the library's own streams) ---- */
+#define GPX_STAGE_GRAM 0        /* gram build of K (n x n) */
+#define GPX_STAGE_GRAM_CROSS 1  /* gram build of k_cross (m x n) */
+#define GPX_STAGE_POTRF_DIAG 2  /* LDS-resident diagonal-block factorisation */
+#define GPX_STAGE_TRSM_PANEL 3  /* panel solve as MFMA GEMM against inv(L_kk) */
+#define GPX_STAGE_TRAILING 4    /* trailing SYRK/GEMM update on fp64 MFMA */
+#define GPX_STAGE_EPILOGUE 5    /* log-det / quadratic form / mean / variance reductions */
+#define GPX_STAGE_FACTOR_TOTAL 6
+#define GPX_N_STAGES 7
+/* mode 0 = off (default), 1 = bracket every launch of each stage with HIP events. */
+int gpx_profile_mode(gpx_handle* h, int mode);
+int gpx_profile_reset(gpx_handle* h);
+/* total milliseconds, number of launches and algorithmic flops+bytes summed over them. */
+int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launches,
+                    double* flops, double* bytes);
+
+/* ---- tuning knobs (ints; unknown names -> GPX_ERR_ARG).  "nb" panel width,
+ * "lookahead" 0/1, "graph" 0/1. */
+int gpx_set_option(gpx_handle* h, const char* name, int64_t value);
+int gpx_get_option(gpx_handle* h, const char* name, int64_t* value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

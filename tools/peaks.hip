@@ -1,0 +1,101 @@
+// peaks.hip -- measured ceilings on this MI355X for the two rooflines the path is priced
+// against: fp64 MFMA (v_mfma_f64_16x16x4_f64) issue rate, fp64 VALU FMA rate, and the
+// HBM write/copy rate of a 16-B-per-lane streaming kernel.   Build: see __graft_entry__.build().
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double a0, double b0) {
+  v4d acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double a = a0 + threadIdx.x * 1e-3, b = b0 - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void fma_loop(double* out, int iters, double a0) {
+  double x[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) x[i] = a0 + i + threadIdx.x * 1e-3;
+  const double m = 1.0000001, c = 1e-9;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = fma(x[i], m, c);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += x[i];
+  if (s == 12345.678) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(v2d* dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  v2d v = {1.0, 2.0};
+  for (; i < n; i += stride) dst[i] = v;
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(v2d* dst, const v2d* src, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = src[i];
+}
+
+template <typename F>
+static float time_ms(F&& f, int reps) {
+  hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  f();
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(a));
+  for (int r = 0; r < reps; ++r) f();
+  CHECK(hipEventRecord(b));
+  CHECK(hipEventSynchronize(b));
+  float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+  return ms / reps;
+}
+
+int main() {
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  printf("device: %s %s CUs=%d clock=%d MHz\n", prop.name, prop.gcnArchName, cus, prop.clockRate / 1000);
+  double* out; CHECK(hipMalloc(&out, 64));
+  const int iters = 4096;
+  for (int wpc = 4; wpc <= 8; wpc *= 2) {   // waves per CU: 4 = one per SIMD, 8 = two per SIMD
+    dim3 grid(cus * wpc / 4), block(256);
+    float ms1 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<1>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
+    float ms4 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<4>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
+    double fl1 = 2048.0 * iters * 1 * (double)grid.x * 4, fl4 = 2048.0 * iters * 4 * (double)grid.x * 4;
+    printf("mfma_f64_16x16x4 waves/CU=%d: 1 acc %.2f TFLOP/s (%.1f cyc/MFMA @2.4GHz), 4 acc %.2f TFLOP/s (%.1f cyc/MFMA/SIMD)\n", wpc,
+           fl1 / ms1 * 1e-9, ms1 * 1e-3 * 2.4e9 / iters / (wpc / 4), fl4 / ms4 * 1e-9, ms4 * 1e-3 * 2.4e9 / (iters * 4) / (wpc / 4));
+  }
+  {
+    dim3 grid(cus * 8), block(256);   // 8 waves per SIMD worth of blocks
+    float ms = time_ms([&] { hipLaunchKernelGGL(fma_loop, grid, block, 0, 0, out, iters, 1.0); }, 5);
+    double fl = 2.0 * 8 * iters * (double)grid.x * 256;
+    printf("v_fma_f64: %.2f TFLOP/s\n", fl / ms * 1e-9);
+  }
+  {
+    const size_t bytes = (size_t)1 << 31;  // 2 GiB
+    v2d *a, *b; CHECK(hipMalloc(&a, bytes)); CHECK(hipMalloc(&b, bytes));
+    const size_t n = bytes / sizeof(v2d);
+    dim3 grid(cus * 8), block(256);
+    float msf = time_ms([&] { hipLaunchKernelGGL(fill_kernel, grid, block, 0, 0, a, n); }, 5);
+    float msc = time_ms([&] { hipLaunchKernelGGL(copy_kernel, grid, block, 0, 0, b, a, n); }, 5);
+    printf("HBM fill (write only): %.2f TB/s ; copy (read+write): %.2f TB/s\n", bytes / msf * 1e-9, 2.0 * bytes / msc * 1e-9);
+    CHECK(hipFree(a)); CHECK(hipFree(b));
+  }
+  return 0;
+}
