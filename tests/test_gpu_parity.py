@@ -182,13 +182,14 @@ def test_not_positive_definite_reports_info(core):
     import gpax_amd
 
     rng = np.random.default_rng(3)
-    x = rng.uniform(-1, 1, (40, 2))
-    x[17] = x[3]  # duplicate point, zero noise and zero jitter -> singular K
+    x = rng.uniform(-1, 1, (200, 2))
+    noise = np.full(200, 0.01)
+    noise[137] = -5.0  # diagonal entry 1 - 5 + jitter < 0: the leading minor of order 138 is not PD
     core.set_train(x)
-    prm = gpax_amd.make_params(0, 1.0, 1.0, None, np.array([0.0]), 0.0)
+    prm = gpax_amd.make_params(0, 1.0, 1.0, None, noise, 1e-6)
     info, _, l = core.fit_factor(prm, want_l=True)
-    assert info > 0 and info <= 40
-    assert not np.isfinite(l).all()
+    assert info == 138
+    assert np.isfinite(l[:137]).all() and not np.isfinite(l[137:, 137:]).all()
 
 
 def test_call_order_errors(core):

@@ -54,6 +54,22 @@ __global__ __launch_bounds__(256) void copy_kernel(v2d* dst, const v2d* src, siz
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// in-kernel clock under an MFMA-dense loop: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime)
+__global__ __launch_bounds__(256) void clock_probe(double* out, unsigned long long* clk, int iters) {
+  v4d acc[4];
+  for (int i = 0; i < 4; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double a = 1.0 + threadIdx.x * 1e-3, b = 2.0 - threadIdx.x * 1e-3;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = acc[0][0] + acc[1][0] + acc[2][0] + acc[3][0];
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (s == 12345.678) out[0] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) { clk[0] = t1 - t0; clk[1] = r1 - r0; }
+}
+
 template <typename F>
 static float time_ms(F&& f, int reps) {
   hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
@@ -73,13 +89,24 @@ int main() {
   printf("device: %s %s CUs=%d clock=%d MHz\n", prop.name, prop.gcnArchName, cus, prop.clockRate / 1000);
   double* out; CHECK(hipMalloc(&out, 64));
   const int iters = 4096;
-  for (int wpc = 4; wpc <= 8; wpc *= 2) {   // waves per CU: 4 = one per SIMD, 8 = two per SIMD
+  for (int wpc = 4; wpc <= 32; wpc *= 2) {   // waves per CU: 4 = one per SIMD, 8 = two per SIMD, ...
     dim3 grid(cus * wpc / 4), block(256);
+    float ms8 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<8>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
+    printf("mfma_f64_16x16x4 waves/CU=%d: 8 acc %.2f TFLOP/s\n", wpc, 2048.0 * iters * 8 * (double)grid.x * 4 / ms8 * 1e-9);
     float ms1 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<1>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
     float ms4 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<4>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
     double fl1 = 2048.0 * iters * 1 * (double)grid.x * 4, fl4 = 2048.0 * iters * 4 * (double)grid.x * 4;
     printf("mfma_f64_16x16x4 waves/CU=%d: 1 acc %.2f TFLOP/s (%.1f cyc/MFMA @2.4GHz), 4 acc %.2f TFLOP/s (%.1f cyc/MFMA/SIMD)\n", wpc,
            fl1 / ms1 * 1e-9, ms1 * 1e-3 * 2.4e9 / iters / (wpc / 4), fl4 / ms4 * 1e-9, ms4 * 1e-3 * 2.4e9 / (iters * 4) / (wpc / 4));
+  }
+  {
+    unsigned long long* clk; CHECK(hipMalloc(&clk, 16));
+    dim3 grid(cus * 2), block(256);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(clock_probe, grid, block, 0, 0, out, clk, 1 << 16);
+    CHECK(hipDeviceSynchronize());
+    unsigned long long hc[2]; CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
+    printf("in-kernel clock under fp64 MFMA load: %.0f MHz; cycles per MFMA per SIMD (2 waves/SIMD, 4 acc): %.1f\n",
+           (double)hc[0] / (double)hc[1] * 100.0, (double)hc[0] / ((double)(1 << 16) * 4 * 2));
   }
   {
     dim3 grid(cus * 8), block(256);   // 8 waves per SIMD worth of blocks
