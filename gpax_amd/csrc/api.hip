@@ -114,6 +114,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   const char* env;
   if ((env = getenv("GPX_NB"))) h->nb = atoi(env) == 64 ? 64 : 128;
   if ((env = getenv("GPX_LOOKAHEAD"))) h->lookahead = atoi(env) != 0;
+  if ((env = getenv("GPX_GRAPH"))) h->use_graph = atoi(env) != 0;
   *out = h;
   return GPX_OK;
 }
@@ -127,6 +128,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
                   h->d_gout, h->d_vec};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   for (auto e : h->ev_panel) (void)hipEventDestroy(e);
   for (auto e : h->ev_trail) (void)hipEventDestroy(e);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -178,8 +180,12 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
 
 // Validate the keyword block against (n rows, d dims) and upload length[d], period[d]
 // (and the per-row noise vector when n_noise == n) to the device.
+static double kernel_diag_value(int kind, double k_scale);
+
+// Device layout of d_hyp: length[d], period[d], then {k_scale, noise_scalar, k_jitter, prior_diag}
+// (prior_diag = k(x*,x*) + new_noise + jitter, the diagonal of k_new, gpax/gp.py:287).
 static int upload_params(gpx_handle* h, hipStream_t s, const gpx_kernel_params* p, int64_t n, int d,
-                         const double** noise_dev, double* noise_scalar) {
+                         const double** noise_dev, double* noise_scalar, double new_noise = 0.0) {
   if (!p) { gpx_set_error(h, "params is NULL"); return GPX_ERR_ARG; }
   if (p->kind != GPX_RBF && p->kind != GPX_MATERN52 && p->kind != GPX_PERIODIC) {
     gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
@@ -195,17 +201,20 @@ static int upload_params(gpx_handle* h, hipStream_t s, const gpx_kernel_params* 
     gpx_set_error(h, "k_noise must have 0, 1 or n entries"); return GPX_ERR_ARG;
   }
   if (p->n_noise > 0 && !p->k_noise) { gpx_set_error(h, "k_noise is NULL"); return GPX_ERR_ARG; }
-  std::vector<double> hyp(2 * (size_t)d);
+  std::vector<double> hyp(2 * (size_t)d + 4);
   for (int k = 0; k < d; ++k) {
     hyp[k] = p->k_length[p->n_length == 1 ? 0 : k];
     hyp[d + k] = (p->kind == GPX_PERIODIC) ? p->k_period[p->n_period == 1 ? 0 : k] : 1.0;
   }
-  GPX_RET(ensure(h, &h->d_hyp, &h->hyp_cap, 2 * (int64_t)d));
-  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_hyp, hyp.data(), hyp.size() * sizeof(double), hipMemcpyHostToDevice, s));
   *noise_dev = nullptr;
-  *noise_scalar = 0.0;
-  if (p->n_noise == 1) *noise_scalar = p->k_noise[0];
-  else if (p->n_noise > 1) {
+  *noise_scalar = (p->n_noise == 1) ? p->k_noise[0] : 0.0;
+  hyp[2 * d + 0] = p->k_scale;
+  hyp[2 * d + 1] = *noise_scalar;
+  hyp[2 * d + 2] = p->k_jitter;
+  hyp[2 * d + 3] = kernel_diag_value(p->kind, p->k_scale) + (new_noise + p->k_jitter);
+  GPX_RET(ensure(h, &h->d_hyp, &h->hyp_cap, 2 * (int64_t)d + 4));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_hyp, hyp.data(), hyp.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  if (p->n_noise > 1) {
     GPX_RET(ensure(h, &h->d_noise, &h->noise_cap, n));
     GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_noise, p->k_noise, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
     *noise_dev = h->d_noise;
@@ -333,7 +342,6 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld;
   const int64_t nblk = npad / nb;
   hipStream_t P = h->s_main, T = h->lookahead ? h->s_trail : h->s_main;
-  GPX_RET(ensure_events(h, (size_t)nblk));
   double* A = h->d_A; double* L = h->d_L;
   std::vector<char> trail_pending((size_t)nblk, 0);
   for (int64_t k = 0; k < nblk; ++k) {
@@ -392,36 +400,54 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
   return GPX_OK;
 }
 
-// Build [K ; k_cross ; r] in d_A, factorise, leave [L ; V^T ; z^T] in d_L.
-static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_rows, bool with_r, double* K_out) {
+// ---- the bordered factorisation, in three parts so that the enqueue part can be captured
+// into a hipGraph: (1) sizes + allocations, (2) hyper-parameter upload, (3) pure enqueue.
+struct FactorPlan {
+  int kind; int apply_noise;
+  int64_t m_rows; bool with_r;
+  const double* noise_dev;   // per-row noise vector on the device, or nullptr
+  bool want_k;               // full (not lower-only) K build for a K_out copy
+};
+
+static int factor_prepare(gpx_handle* h, int64_t m_rows, bool with_r) {
   if (h->n <= 0 || !h->d_x) { gpx_set_error(h, "no training inputs: call gpx_set_train first"); return GPX_ERR_STATE; }
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
-  const int64_t n = h->n, nb = h->nb; const int d = h->d;
+  const int64_t n = h->n, nb = h->nb;
   const int64_t npad = round_up(n, nb);
   const int64_t E = m_rows + (with_r ? 1 : 0);
   const int64_t epad = E > 0 ? round_up(E, 64) : 0;
   const int64_t rows = npad + epad, ld = npad;
-  hipStream_t s = h->s_main;
   GPX_RET(ensure(h, &h->d_A, &h->a_cap, rows * ld));
   GPX_RET(ensure(h, &h->d_L, &h->l_cap, rows * ld));
   GPX_RET(ensure(h, &h->d_W, &h->w_cap, npad * nb));
   GPX_RET(ensure(h, &h->d_z, &h->z_cap, npad));
+  GPX_RET(ensure(h, &h->d_mean, &h->out_cap, 2 * std::max<int64_t>(m_rows, 1)));
+  GPX_RET(ensure_events(h, (size_t)(npad / nb)));
   h->have_factor = false; h->have_z = false;
   h->npad = npad; h->epad = epad; h->ld = ld;
+  return GPX_OK;
+}
 
-  const double* noise_dev; double noise_scalar;
-  GPX_RET(upload_params(h, s, p, n, d, &noise_dev, &noise_scalar));
+// Build [K ; k_cross ; r] in d_A, factorise, leave [L ; V^T ; z^T] in d_L.  Enqueue only
+// (kernel launches, memsets, device-to-device copies, stream events): capturable.
+static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
+  const int64_t n = h->n, npad = h->npad, ld = h->ld; const int d = h->d;
+  const int64_t m_rows = fp.m_rows;
+  const int64_t E = m_rows + (fp.with_r ? 1 : 0);
+  const int64_t rows = npad + h->epad;
+  hipStream_t s = h->s_main;
+  const double* dev_scalars = h->d_hyp + 2 * d;
 
-  // K (diagonal rule always on for k_train: gpax/gp.py:293 calls f(x, x, k_noise, k_jitter))
+  // K (diagonal rule on for k_train: gpax/gp.py:293 calls f(x, x, k_noise, k_jitter))
   GramLaunch g;
-  g.kind = p->kind; g.d = d; g.k_scale = p->k_scale; g.hyp = h->d_hyp;
+  g.kind = fp.kind; g.d = d; g.k_scale = 0.0; g.hyp = h->d_hyp; g.dev_scalars = dev_scalars;
   g.x1 = h->d_x; g.x2 = h->d_x; g.n1 = n; g.n2 = n; g.out = h->d_A; g.ld = ld;
-  g.lower_only = K_out ? 0 : 1; g.diag_rule = p->apply_noise ? 1 : 0;
-  g.noise = noise_dev; g.noise_scalar = noise_scalar; g.jitter = p->k_jitter;
+  g.lower_only = fp.want_k ? 0 : 1; g.diag_rule = fp.apply_noise ? 1 : 0;
+  g.noise = fp.noise_dev; g.noise_scalar = 0.0; g.jitter = 0.0;
   {
     const double T = (double)((n + 63) / 64);
-    const double entries = K_out ? (double)n * n : T * (T + 1) / 2.0 * 4096.0;
-    prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(p->kind, d) * entries, 8.0 * entries + 16.0 * n * d);
+    const double entries = fp.want_k ? (double)n * n : T * (T + 1) / 2.0 * 4096.0;
+    prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(fp.kind, d) * entries, 8.0 * entries + 16.0 * n * d);
     GPX_RET(launch_gram(h, s, g));
     prof_end(h, s);
   }
@@ -433,29 +459,44 @@ static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_ro
   if (m_rows > 0) {
     GramLaunch c = g;
     c.x1 = h->d_xnew; c.n1 = m_rows; c.out = h->d_A + npad * ld; c.lower_only = 0; c.diag_rule = 0;
-    c.noise = nullptr; c.noise_scalar = 0.0;
-    prof_begin(h, s, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(p->kind, d) * m_rows * n,
+    c.noise = nullptr;
+    prof_begin(h, s, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(fp.kind, d) * m_rows * n,
                8.0 * m_rows * n + 8.0 * (m_rows + n) * d);
     GPX_RET(launch_gram(h, s, c));
     prof_end(h, s);
   }
-  if (with_r) GPX_RET(launch_set_row(h, s, h->d_A + (npad + m_rows) * ld, h->d_r, n, npad));
+  if (fp.with_r) GPX_RET(launch_set_row(h, s, h->d_A + (npad + m_rows) * ld, h->d_r, n, npad));
   GPX_RET(launch_fill_rect(h, s, h->d_A, ld, npad + E, rows, 0, n, 0.0));  // unused border rows
   GPX_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
 
   GPX_RET(factor_loop(h, rows));
 
+  if (fp.with_r) {  // keep z = L^-1 r for later posterior calls against the cached factor
+    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_z, h->d_L + (npad + m_rows) * ld, (size_t)npad * sizeof(double),
+                                    hipMemcpyDeviceToDevice, s));
+  }
+  return GPX_OK;
+}
+
+static void factor_commit(gpx_handle* h, const gpx_kernel_params* p, int64_t m_rows, bool with_r) {
   h->have_factor = true;
   h->m_in_factor = m_rows; h->r_in_factor = with_r;
   h->f_kind = p->kind; h->f_scale = p->k_scale; h->f_jitter = p->k_jitter;
   h->f_length.assign(p->k_length, p->k_length + p->n_length);
   h->f_period.clear();
   if (p->kind == GPX_PERIODIC) h->f_period.assign(p->k_period, p->k_period + p->n_period);
-  if (with_r) {  // keep z = L^-1 r for later posterior calls against the cached factor
-    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_z, h->d_L + (npad + m_rows) * ld, (size_t)npad * sizeof(double),
-                                    hipMemcpyDeviceToDevice, s));
-    h->have_z = true;
-  }
+  h->have_z = with_r;
+}
+
+static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_rows, bool with_r, double* K_out,
+                         double new_noise = 0.0) {
+  GPX_RET(factor_prepare(h, m_rows, with_r));
+  FactorPlan fp;
+  double noise_scalar;
+  GPX_RET(upload_params(h, h->s_main, p, h->n, h->d, &fp.noise_dev, &noise_scalar, new_noise));
+  fp.kind = p->kind; fp.apply_noise = p->apply_noise; fp.m_rows = m_rows; fp.with_r = with_r; fp.want_k = K_out != nullptr;
+  GPX_RET(factor_enqueue(h, fp, K_out));
+  factor_commit(h, p, m_rows, with_r);
   return GPX_OK;
 }
 
@@ -644,28 +685,70 @@ extern "C" int gpx_prior_cov(gpx_handle* h, const gpx_kernel_params* p, double n
 
 // ------------------------------------------------------------------ fused fit+predict
 
+static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
+  const int64_t m = fp.m_rows;
+  hipStream_t s = h->s_main;
+  GPX_RET(factor_enqueue(h, fp, nullptr));
+  EpilogueLaunch e;
+  e.L = h->d_L; e.ld = h->ld; e.n = h->n; e.z = h->d_L + (h->npad + m) * h->ld;
+  e.vt = h->d_L + h->npad * h->ld; e.vt_ld = h->ld; e.m = m;
+  e.m_new = h->have_mnew ? h->d_mnew : nullptr;
+  e.prior_diag = 0.0; e.dev_prior_diag = h->d_hyp + 2 * h->d + 3;
+  e.scal = h->d_scal; e.mean = h->d_mean; e.var = h->d_var;
+  prof_begin(h, s, GPX_STAGE_EPILOGUE, 4.0 * (m + 1.0) * h->n, 8.0 * (m + 2.0) * h->n);
+  GPX_RET(launch_epilogue(h, s, e));
+  prof_end(h, s);
+  return GPX_OK;
+}
+
 extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, double new_noise) {
   if (!h) return GPX_ERR_ARG;
   if (!h->have_r) { gpx_set_error(h, "gpx_fit_predict_async: call gpx_set_targets first"); return GPX_ERR_STATE; }
   const int64_t m = h->m;
   hipStream_t s = h->s_main;
-  prof_begin(h, s, GPX_STAGE_FACTOR_TOTAL, 0.0, 0.0);
-  GPX_RET(factor_common(h, p, m, true, nullptr));
-  GPX_RET(ensure(h, &h->d_mean, &h->out_cap, 2 * std::max<int64_t>(m, 1)));
+  GPX_RET(factor_prepare(h, m, true));
   h->d_var = h->d_mean + std::max<int64_t>(m, 1);
-  EpilogueLaunch e;
-  e.L = h->d_L; e.ld = h->ld; e.n = h->n; e.z = h->d_L + (h->npad + m) * h->ld;
-  e.vt = h->d_L + h->npad * h->ld; e.vt_ld = h->ld; e.m = m;
-  e.m_new = h->have_mnew ? h->d_mnew : nullptr;
-  e.prior_diag = kernel_diag_value(p->kind, p->k_scale) + (new_noise + p->k_jitter);
-  e.scal = h->d_scal; e.mean = h->d_mean; e.var = h->d_var;
-  prof_begin(h, s, GPX_STAGE_EPILOGUE, 4.0 * (m + 1.0) * h->n, 8.0 * (m + 2.0) * h->n);
-  GPX_RET(launch_epilogue(h, s, e));
-  prof_end(h, s);
-  if (h->prof_mode) {  // close the FACTOR_TOTAL bracket (first pending of this call)
-    for (size_t i = h->pending.size(); i-- > 0;)
-      if (h->pending[i].stage == GPX_STAGE_FACTOR_TOTAL) { (void)hipEventRecord(h->pending[i].b, s); break; }
+  FactorPlan fp;
+  double noise_scalar;
+  GPX_RET(upload_params(h, s, p, h->n, h->d, &fp.noise_dev, &noise_scalar, new_noise));
+  fp.kind = p->kind; fp.apply_noise = p->apply_noise; fp.m_rows = m; fp.with_r = true; fp.want_k = false;
+
+  if (h->use_graph && !h->prof_mode) {
+    // One captured graph per (shape, kernel kind, buffer addresses); hyper-parameter VALUES live in
+    // d_hyp / d_noise / d_r / d_mnew, so the same graph is replayed for every hyper-parameter draw.
+    char key[512];
+    snprintf(key, sizeof(key), "%d|%d|%lld|%lld|%d|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p", fp.kind, fp.apply_noise,
+             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
+             (void*)h->d_x, (void*)h->d_xnew, (void*)h->d_r, (void*)(h->have_mnew ? h->d_mnew : nullptr),
+             (void*)h->d_hyp, (void*)fp.noise_dev, (void*)h->d_mean, (void*)h->d_z);
+    auto it = h->graphs.find(key);
+    if (it == h->graphs.end()) {
+      hipGraph_t graph = nullptr;
+      GPX_HIP_CHECK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      int rc = fit_predict_enqueue(h, fp);
+      hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (rc != GPX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      if (ce != hipSuccess) { gpx_set_error(h, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return GPX_ERR_HIP; }
+      hipGraphExec_t exec = nullptr;
+      ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(graph);
+      if (ce != hipSuccess) { gpx_set_error(h, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); return GPX_ERR_HIP; }
+      if (h->graphs.size() >= 16) {  // bound the cache
+        for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+      }
+      it = h->graphs.emplace(key, exec).first;
+    }
+    GPX_HIP_CHECK(h, hipGraphLaunch(it->second, s));
+  } else {
+    prof_begin(h, s, GPX_STAGE_FACTOR_TOTAL, 0.0, 0.0);
+    GPX_RET(fit_predict_enqueue(h, fp));
+    if (h->prof_mode) {  // close the FACTOR_TOTAL bracket (first pending of this call)
+      for (size_t i = h->pending.size(); i-- > 0;)
+        if (h->pending[i].stage == GPX_STAGE_FACTOR_TOTAL) { (void)hipEventRecord(h->pending[i].b, s); break; }
+    }
   }
+  factor_commit(h, p, m, true);
   return GPX_OK;
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <string>
 #include <vector>
 
@@ -40,6 +41,7 @@ struct GramLaunch {
   int d;
   double k_scale;
   const double* hyp;    // device: length[d] then period[d]
+  const double* dev_scalars = nullptr;  // device {k_scale, noise_scalar, jitter}: overrides the by-value fields
   const double* x1;     // device (n1,d)
   const double* x2;     // device (n2,d)
   int64_t n1, n2;
@@ -92,6 +94,7 @@ struct EpilogueLaunch {
   int64_t m;                     // test rows
   const double* m_new;           // device (m) or NULL
   double prior_diag;             // k(x*,x*) incl. noise+jitter of the diagonal rule
+  const double* dev_prior_diag = nullptr;  // device copy (graph replays); overrides prior_diag
   double* scal;                  // device: [0]=logdet [1]=quad
   double* mean; double* var;     // device (m)
 };
@@ -111,7 +114,7 @@ struct gpx_handle {
   // options
   int nb = 128;
   int lookahead = 1;
-  int use_graph = 0;
+  int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
   // resident inputs
   double* d_x = nullptr; int64_t n = 0; int d = 0; int64_t x_cap = 0;
@@ -149,6 +152,9 @@ struct gpx_handle {
   int* d_info = nullptr;
   double* d_mean = nullptr; double* d_var = nullptr; int64_t out_cap = 0;  // d_var aliases d_mean + m
   double* h_pinned = nullptr; int64_t pinned_cap = 0;  // pinned staging for small results
+
+  // captured hipGraphs of the fused fit+predict step, keyed by shape + buffer addresses
+  std::map<std::string, hipGraphExec_t> graphs;
 
   // events for the two-stream lookahead
   std::vector<hipEvent_t> ev_panel, ev_trail;

@@ -26,6 +26,7 @@
 struct GramArgs {
   const double* x1; const double* x2;
   const double* hyp;     // length[d], period[d]
+  const double* dev_scalars;  // device {k_scale, noise_scalar, jitter} or nullptr (then the by-value fields)
   const double* noise;   // per-row noise or nullptr
   double* out;
   int64_t n1, n2, ld;
@@ -97,6 +98,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     __syncthreads();
   }
 
+  // hyper-parameter scalars: from device memory when the launch is part of a replayed hipGraph
+  // (one captured graph then serves every hyper-parameter value), else by value
+  const double k_scale = g.dev_scalars ? g.dev_scalars[0] : g.k_scale;
+  const double noise_scalar = g.dev_scalars ? g.dev_scalars[1] : g.noise_scalar;
+  const double jitter = g.dev_scalars ? g.dev_scalars[2] : g.jitter;
   const int64_t col = j0 + 2 * cj;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -108,17 +114,17 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
       const double r2 = acc[r][c];
       double k;
       if (KIND == GPX_RBF) {
-        k = g.k_scale * exp(-0.5 * r2);                       // kernels.py:123
+        k = k_scale * exp(-0.5 * r2);                       // kernels.py:123
       } else if (KIND == GPX_MATERN52) {
         const double rr = sqrt(r2 + 1e-12);                   // kernels.py:142
         const double s5r = 2.2360679774997896964 * rr;             // 5**0.5 * r
-        k = g.k_scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);  // kernels.py:144
+        k = k_scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);  // kernels.py:144
       } else {
-        k = g.k_scale * exp(-2.0 * r2);                       // kernels.py:165
+        k = k_scale * exp(-2.0 * r2);                       // kernels.py:165
       }
       if (g.diag_rule && row == col + c) {
-        const double nz = g.noise ? g.noise[row] : g.noise_scalar;
-        k += (nz + g.jitter);                                 // kernels.py:124-125
+        const double nz = g.noise ? g.noise[row] : noise_scalar;
+        k += (nz + jitter);                                 // kernels.py:124-125
       }
       kv[c] = k;
     }
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   if (L.n1 <= 0 || L.n2 <= 0) return GPX_OK;
   GramArgs g;
-  g.x1 = L.x1; g.x2 = L.x2; g.hyp = L.hyp; g.noise = L.noise; g.out = L.out;
+  g.x1 = L.x1; g.x2 = L.x2; g.hyp = L.hyp; g.dev_scalars = L.dev_scalars; g.noise = L.noise; g.out = L.out;
   g.n1 = L.n1; g.n2 = L.n2; g.ld = L.ld; g.d = L.d;
   g.lower_only = L.lower_only; g.diag_rule = L.diag_rule;
   g.k_scale = L.k_scale; g.noise_scalar = L.noise_scalar; g.jitter = L.jitter;

@@ -89,8 +89,13 @@ __device__ unsigned long long* g_stamps;
   do {                                                                               \
     if (threadIdx.x == 0) g_stamps[slot] = __builtin_amdgcn_s_memtime();             \
   } while (0)
+#define GPX_STAMP_T(slot, t)                                                         \
+  do {                                                                               \
+    if (threadIdx.x == (t)) g_stamps[slot] = __builtin_amdgcn_s_memtime();           \
+  } while (0)
 #else
 #define GPX_STAMP(slot) do { } while (0)
+#define GPX_STAMP_T(slot, t) do { } while (0)
 #endif
 
 // ---- tile-level building blocks (one wave each; all operands are LDS tiles) ----
@@ -146,60 +151,197 @@ __device__ __forceinline__ void tile_winv(double* Lt, double* Wt, int jb, int cb
   for (int r = 0; r < 4; ++r) Tp[eix(fk + 4 * r, fr)] = a0[r] + a1[r];
 }
 
-// 16x16 leaf: Cholesky of the diagonal tile AND its inverse, one matrix row per lane (the 4
-// DPP rows of the wave work redundantly), pivot column / pivot row broadcast by DPP.
-__device__ __forceinline__ void leaf_potrf_inv(double* Ld, double* Wd, int lane, int* info, int gcol0) {
+// ---- 16x16 leaf, split over TWO waves that sit on different SIMDs -------------------------
+// One matrix row per lane (the 4 DPP rows of a wave work redundantly); pivot column / pivot row
+// are broadcast by DPP.  A single wave issues one fp64 instruction every ~7.2 cycles, so the leaf
+// is issue-bound: wave 0 runs only the Cholesky recurrence (the critical path of the whole
+// factorisation) and publishes each finished column through LDS; wave 1 follows behind and
+// forward-substitutes the identity with them, giving inv(L_jj).
+//
+// Hand-off area (LDS, 16 columns x 40 doubles; the 4 redundant DPP rows store identical values to
+// the same slots, so no store is predicated): per column j   [0..15] l_ij by row   [16..31] 1/l_jj
+// (16 copies)   [32..39] 16 x int epoch; plus one always-zero double behind the columns.  LDS executes a wave's DS
+// instructions in order, so a reader that sees a group's epoch sees the group's data.  Epochs increase monotonically over the
+// kernel (leaf jb, column j -> 16 jb + j + 1): nothing is ever reset.
+#define LEAF_COL_DOUBLES 40
+#define LEAF_ZERO_SLOT (16 * LEAF_COL_DOUBLES)
+#define LEAF_SHARE_DOUBLES (16 * LEAF_COL_DOUBLES + 2)
+
+// wave 1 consumes the columns in groups {0-3} {4-7} {8-11} {12,13} {14} {15}: one LDS round trip per
+// group, short groups at the end so that it finishes right behind wave 0
+__host__ __device__ constexpr int leaf_group_start(int j) { return j < 12 ? (j & ~3) : (j < 14 ? 12 : j); }
+__host__ __device__ constexpr int leaf_group_size(int j) { return j < 12 ? 4 : (j < 14 ? 2 : 1); }
+__host__ __device__ constexpr bool leaf_group_end(int j) { return j == leaf_group_start(j) + leaf_group_size(j) - 1; }
+
+template <int L>
+__device__ __forceinline__ double pivot_bcast(double x) {   // volatile: keeps its place among the fmacs
+  double r;
+  asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "i"(L));
+  return r;
+}
+template <int L>
+__device__ __forceinline__ double pivot_bcast_padded(double x) {   // with the 2 wait states inside
+  double r;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "i"(L));
+  return r;
+}
+// acc -= row_newbcast<L>(src) * mul   (neg modifier on src1: no separate negation)
+template <int L>
+__device__ __forceinline__ void fnmac_bcast(double& acc, double src, double mul) {
+  asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+               : "+v"(acc)
+               : "v"(src), "v"(mul), "i"(L));
+}
+
+// wave 0: L_jj.  No predication at all: finished rows (i <= j) only ever corrupt their own
+// above-diagonal entries, which are don't-care; lane j gets l_jj = d * rinv from the same multiply.
+__device__ __forceinline__ void leaf_potrf(double* Ld, double* share, int lane, int base_epoch, int* info,
+                                           int gcol0) {
   const int i = lane & 15;
-  double a[16], w[16];
-  int first_bad = -1;
-  double my_rinv = 1.0;  // 1 / l_ii of this lane's own row (row scaling of inv(L_jj) is deferred)
+  double a[16];
+  // eix(i, c) keeps even/odd column pairs adjacent (the XOR mask is even): 8 x 16-B accesses per row
 #pragma unroll
-  for (int c = 0; c < 16; ++c) {
-    a[c] = Ld[eix(i, c)];
-    w[c] = (c == i) ? 1.0 : 0.0;
+  for (int c = 0; c < 16; c += 2) {
+    const v2d v = *reinterpret_cast<const v2d*>(Ld + eix(i, c));
+    a[c] = v.x; a[c + 1] = v.y;
   }
+  double d = row_bcast64<0>(a[0]);                   // pivot a_00
   static_for<0, 16>([&](auto J) {
     constexpr int j = decltype(J)::value;
-    dpp_fence(a[j]);                                // a[j] was written inside an asm (invisible to hipcc's hazard pass)
-    const double d = row_bcast64<j>(a[j]);          // pivot a_jj (after updates)
-    first_bad = (!(d > 0.0) && first_bad < 0) ? j : first_bad;  // non-PD (or NaN) pivot
-    double ljj, rinv;
-    sqrt_rsqrt(d, ljj, rinv);                       // NaN from here on when d <= 0 (JAX semantics)
-    const bool eq = (i == j), gt = (i > j);
-    const double l = a[j] * rinv;                   // column j of L (meaningful in lanes i > j)
-    a[j] = eq ? ljj : l;
-    my_rinv = eq ? rinv : my_rinv;
-    // Rows <= j are finished: they get a zero multiplier instead of a predicate on every
-    // update (entries above the diagonal hold don't-care values and are never read).
-    const double lm = gt ? l : 0.0;                 // l_ij (0 for finished rows)
-    const double nl = -lm;
-    const double nlr = nl * rinv;                   // -l_ij / l_jj
-    // rank-1 update of the trailing rows:  a_ic -= l_ij * l_cj   (c > j); c = j+1 first, it
-    // feeds the next pivot
-    double lms = lm;
-    dpp_fence(lms);                                 // lm was just written by VALU selects
-    static_for<j + 1, 16>([&](auto C) {
+    // 1/sqrt(d): v_rsq_f64 + one cubic step (see sqrt_rsqrt)
+    const double y = __builtin_amdgcn_rsq(d);
+    const double t = d * y;
+    const double e = fma(-t, y, 1.0);
+    const double cc = fma(0.375, e, 0.5);
+    const double ye = y * e;
+    const double rinv = fma(ye, cc, y);
+    double l = a[j] * rinv;                          // column j of L; lane j: d * rinv = l_jj
+    a[j] = l;
+    // publish column j (l per lane, then 1/l_jj per lane); its epoch only at the end of a
+    // consumer group (leaf_group_end)
+    share[j * LEAF_COL_DOUBLES + i] = l;
+    share[j * LEAF_COL_DOUBLES + 16 + i] = rinv;
+    if constexpr (leaf_group_end(j)) {
+      asm volatile("" ::: "memory");
+      reinterpret_cast<int*>(share + j * LEAF_COL_DOUBLES + 32)[i] = base_epoch + j + 1;
+    }
+    dpp_fence(l);                                    // l was just written by a VALU multiply
+    // rank-1 update a_ic -= l_ij * l_cj (c > j).  c = j+1 first: it is the next pivot, whose
+    // broadcast is issued as soon as the DPP-read hazard allows (two fmacs later).
+    if constexpr (j + 1 < 16) fnmac_bcast<j + 1>(a[j + 1], l, l);
+    if constexpr (j + 2 < 16) fnmac_bcast<j + 2>(a[j + 2], l, l);
+    if constexpr (j + 3 < 16) fnmac_bcast<j + 3>(a[j + 3], l, l);
+    if constexpr (j + 3 < 16) d = pivot_bcast<j + 1>(a[j + 1]);
+    else if constexpr (j + 1 < 16) d = pivot_bcast_padded<j + 1>(a[j + 1]);
+    static_for<j + 4, 16>([&](auto C) {
       constexpr int c = decltype(C)::value;
-      fmac_bcast<c>(a[c], lms, nl);                 // a[c] += bcast_c(l) * (-l_ij)
-    });
-    // forward substitution of the identity on the UNSCALED rows u_i = l_ii * w_i:
-    //   u_i -= (l_ij / l_jj) * u_j   (i > j);   w_i = u_i / l_ii is applied once at the end
-    // (w[c] was last written >= 2 instructions ago except after short groups: fence once)
-    dpp_fence(w[0]);
-    static_for<0, j + 1>([&](auto C) {
-      constexpr int c = decltype(C)::value;
-      fmac_bcast<j>(w[c], w[c], nlr);               // w[c] += bcast_j(w[c]) * (-l_ij / l_jj)
+      fnmac_bcast<c>(a[c], l, l);
     });
   });
-#pragma unroll
-  for (int c = 0; c < 16; ++c) w[c] *= my_rinv;
-  // LAPACK-style info: 1-based global index of the first non-positive pivot
-  if (first_bad >= 0 && lane == 0 && *info == 0) *info = gcol0 + first_bad + 1;
+  // LAPACK-style info: the first non-positive (or NaN) pivot shows as the first diagonal entry
+  // that is not a positive number (NaN propagates to every later pivot)
+  const unsigned long long bad = __ballot(!(a[i] > 0.0)) & 0xffffull;
+  if (bad && lane == 0 && *info == 0) *info = gcol0 + __ffsll((long long)bad);
+  // entries above the diagonal are don't-care here; the write-out phase zeroes them
   if (lane < 16) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-      Ld[eix(i, c)] = (c <= i) ? a[c] : 0.0;
-      Wd[eix(i, c)] = (c <= i) ? w[c] : 0.0;
+    for (int c = 0; c < 16; c += 2) {
+      v2d v; v.x = a[c]; v.y = a[c + 1];
+      *reinterpret_cast<v2d*>(Ld + eix(i, c)) = v;
+    }
+  }
+}
+
+// One LDS round trip for a group of CNT columns starting at J0: the group's epoch, and (l_i, 1/l_jj)
+// of every column (loads and their wait in ONE asm statement: hipcc does not count loads inside asm).
+// la[] are per-lane byte addresses of l_ij, already redirected to the always-zero slot for finished
+// rows (i <= j), so the multiplier of a finished row is exactly 0 with no select.
+template <int J0, int CNT>
+__device__ __forceinline__ void fetch_group(unsigned lds_base, unsigned ep_base, const unsigned (&la)[16], int& epoch,
+                                            double (&l)[4], double (&r)[4]) {
+  constexpr int B = LEAF_COL_DOUBLES * 8;
+  if constexpr (CNT == 4) {
+    asm volatile(
+        "ds_read_b32 %0, %10 offset:%15\n\t"
+        "ds_read_b64 %1, %11\n\tds_read_b64 %2, %9 offset:%16\n\t"
+        "ds_read_b64 %3, %12\n\tds_read_b64 %4, %9 offset:%17\n\t"
+        "ds_read_b64 %5, %13\n\tds_read_b64 %6, %9 offset:%18\n\t"
+        "ds_read_b64 %7, %14\n\tds_read_b64 %8, %9 offset:%19\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(epoch), "=&v"(l[0]), "=&v"(r[0]), "=&v"(l[1]), "=&v"(r[1]), "=&v"(l[2]), "=&v"(r[2]), "=&v"(l[3]), "=&v"(r[3])
+        : "v"(lds_base), "v"(ep_base), "v"(la[J0]), "v"(la[J0 + 1]), "v"(la[J0 + 2]), "v"(la[J0 + 3]), "i"((J0 + 3) * B),
+          "i"(J0 * B + 128), "i"((J0 + 1) * B + 128), "i"((J0 + 2) * B + 128), "i"((J0 + 3) * B + 128)
+        : "memory");
+  } else if constexpr (CNT == 2) {
+    asm volatile(
+        "ds_read_b32 %0, %6 offset:%9\n\t"
+        "ds_read_b64 %1, %7\n\tds_read_b64 %2, %5 offset:%10\n\t"
+        "ds_read_b64 %3, %8\n\tds_read_b64 %4, %5 offset:%11\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(epoch), "=&v"(l[0]), "=&v"(r[0]), "=&v"(l[1]), "=&v"(r[1])
+        : "v"(lds_base), "v"(ep_base), "v"(la[J0]), "v"(la[J0 + 1]), "i"((J0 + 1) * B), "i"(J0 * B + 128), "i"((J0 + 1) * B + 128)
+        : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b32 %0, %4 offset:%6\n\t"
+        "ds_read_b64 %1, %5\n\tds_read_b64 %2, %3 offset:%7\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(epoch), "=&v"(l[0]), "=&v"(r[0])
+        : "v"(lds_base), "v"(ep_base), "v"(la[J0]), "i"(J0 * B), "i"(J0 * B + 128)
+        : "memory");
+  }
+}
+
+// wave 1: inv(L_jj) by forward substitution of the identity on the UNSCALED rows u_i = l_ii w_i:
+//   u_i -= (l_ij / l_jj) u_j  (i > j);  w_i = u_i / l_ii once at the end.
+// Entries above the diagonal are never touched (updates of row i only reach columns c <= j < i),
+// so they stay exactly 0 and nothing is predicated.
+__device__ __forceinline__ void leaf_winv(double* Wd, double* share, int lane, int base_epoch) {
+  const int i = lane & 15;
+  // per-lane LDS byte addresses (the low 32 bits of a generic LDS pointer are the LDS offset)
+  const unsigned lds_base = (unsigned)(uintptr_t)(share + i);   // l_i of column 0; +128 B: 1/l_jj copy i
+  const unsigned ep_base = (unsigned)(uintptr_t)(share + 32) + 4 * i;   // epoch copy i of column 0
+  const unsigned zero_addr = (unsigned)(uintptr_t)(share + LEAF_ZERO_SLOT);
+  unsigned la[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) la[j] = (i > j) ? lds_base + j * (LEAF_COL_DOUBLES * 8) : zero_addr;
+  double w[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w[c] = (c == i) ? 1.0 : 0.0;
+  // hipcc may sink these VALU initialisations down to the first use, which is a DPP read inside an
+  // asm it cannot see into: pin them here, two wait states ahead of every DPP read
+  asm volatile("s_nop 1"
+               : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
+                 "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
+  double gl[4], gr[4];
+  static_for<0, 16>([&](auto J) {
+    constexpr int j = decltype(J)::value;
+    constexpr int j0 = leaf_group_start(j), cnt = leaf_group_size(j);
+    if constexpr (j == j0) {
+      int epoch;
+      fetch_group<j0, cnt>(lds_base, ep_base, la, epoch, gl, gr);
+      // Wave 0 publishes in order and never waits on this wave, so the group's last epoch arrives;
+      // the spin bound only guards against a hang if that ever stopped being true.
+      for (int spin = 0; __any(epoch != base_epoch + j0 + cnt) && spin < (1 << 20); ++spin) {
+        __builtin_amdgcn_s_sleep(1);
+        fetch_group<j0, cnt>(lds_base, ep_base, la, epoch, gl, gr);
+      }
+    }
+    double m = gl[j - j0] * gr[j - j0];              // l_ij / l_jj (exactly 0 for finished rows)
+    // DPP source of the group is w[c], last written by column j-1's group; only the first columns
+    // have fewer than two instructions in between
+    if constexpr (j <= 2) dpp_fence(w[0]);
+    static_for<0, j + 1>([&](auto C) {
+      constexpr int c = decltype(C)::value;
+      fnmac_bcast<j>(w[c], w[c], m);                 // w[c] -= bcast_j(w[c]) * (l_ij / l_jj)
+    });
+  });
+  const double my_rinv = share[i * LEAF_COL_DOUBLES + 16 + i];   // 1 / l_ii (all columns are published by now)
+  if (lane < 16) {
+#pragma unroll
+    for (int c = 0; c < 16; c += 2) {
+      v2d v; v.x = w[c] * my_rinv; v.y = w[c + 1] * my_rinv;
+      *reinterpret_cast<v2d*>(Wd + eix(i, c)) = v;
     }
   }
 }
@@ -215,13 +357,15 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
                                                                  int* info, int col0) {
   constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
   constexpr int TPW = (NTRI + NWAVES - 1) / NWAVES;   // lower tiles per wave (load phase)
-  __shared__ double sm[2 * NTRI * 256];
+  __shared__ double sm[2 * NTRI * 256 + LEAF_SHARE_DOUBLES];
   double* Lt = sm;
   double* Wt = sm + NTRI * 256;
+  double* sh = sm + 2 * NTRI * 256;   // leaf hand-off area
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
   GPX_STAMP(0);
+  for (int t = tid; t < LEAF_SHARE_DOUBLES; t += NWAVES * 64) sh[t] = 0.0;   // epochs start at 0
 
   // ---- load the lower tiles of A_kk: all global loads of a wave in flight, then the LDS writes
   {
@@ -259,7 +403,8 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
   }
   __syncthreads();
   GPX_STAMP(1);
-  if (wave == 0) leaf_potrf_inv(Lt + tix(0, 0) * 256, Wt + tix(0, 0) * 256, lane, info, col0);
+  if (wave == 0) { leaf_potrf(Lt + tix(0, 0) * 256, sh, lane, 0, info, col0); GPX_STAMP(40); }
+  else if (wave == 1) { leaf_winv(Wt + tix(0, 0) * 256, sh, lane, 0); GPX_STAMP_T(41, 64); }
   __syncthreads();
 
 #pragma unroll 1
@@ -278,18 +423,20 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
         double* Cp = Lt + tix(jb + 1, jb + 1) * 256;
         const double* Ap = Lt + tix(jb + 1, jb) * 256;
         tile_syrk(Cp, Ap, Ap, fr, fk);
-        leaf_potrf_inv(Cp, Wt + tix(jb + 1, jb + 1) * 256, lane, info, col0 + (jb + 1) * 16);
+        leaf_potrf(Cp, sh, lane, (jb + 1) * 16, info, col0 + (jb + 1) * 16);
+      } else if (wave == 1) {
+        leaf_winv(Wt + tix(jb + 1, jb + 1) * 256, sh, lane, (jb + 1) * 16);
       } else {
         const int tn = NT - 1 - jb;
         const int ntiles = tn * (tn + 1) / 2;
-        for (int q = wave; q < ntiles + jb; q += NWAVES - 1) {   // q = 0 is wave 0's tile
+        for (int q = wave - 1; q < ntiles + jb; q += NWAVES - 2) {   // q = 0 is wave 0's tile
           if (q < ntiles) {
             int ib2 = 0, q2 = q;
             while (q2 > ib2) { q2 -= ib2 + 1; ++ib2; }
             const int ib = jb + 1 + ib2, lb = jb + 1 + q2;
             tile_syrk(Lt + tix(ib, lb) * 256, Lt + tix(ib, jb) * 256, Lt + tix(lb, jb) * 256, fr, fk);
           } else {
-            tile_winv(Lt, Wt, jb, q - ntiles, fr, fk);   // row jb of W (longest chains last is fine: off the critical path)
+            tile_winv(Lt, Wt, jb, q - ntiles, fr, fk);   // row jb of W: off the critical path
           }
         }
       }
@@ -313,7 +460,10 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
       const double* ws = Wt + t * 256;
       double lv[4], wv[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { lv[q] = ls[eix(r, c4 + q)]; wv[q] = ws[eix(r, c4 + q)]; }
+      for (int q = 0; q < 4; ++q) {
+        lv[q] = ls[eix(r, c4 + q)]; wv[q] = ws[eix(r, c4 + q)];
+        if (ib == jb && c4 + q > r) lv[q] = 0.0;   // the leaf leaves don't-care values above the diagonal
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { ldst[q] = lv[q]; wdst[q] = wv[q]; }
     }

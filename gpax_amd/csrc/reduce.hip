@@ -44,7 +44,8 @@ __global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* L, int64
 
 __global__ __launch_bounds__(256) void post_reduce_kernel(const double* vt, int64_t ld, int64_t n,
                                                          const double* z, const double* m_new,
-                                                         double prior_diag, double* mean, double* var) {
+                                                         double prior_diag, const double* dev_prior_diag,
+                                                         double* mean, double* var) {
   const int64_t row = blockIdx.x;
   const double* v = vt + row * ld;
   double dot = 0.0, ss = 0.0;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const double* vt, int6
   block_sum2<256>(dot, ss);
   if (threadIdx.x == 0) {
     mean[row] = (m_new ? m_new[row] : 0.0) + dot;
-    var[row] = prior_diag - ss;
+    var[row] = (dev_prior_diag ? dev_prior_diag[0] : prior_diag) - ss;
   }
 }
 
@@ -65,7 +66,7 @@ int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
   GPX_HIP_CHECK(h, hipGetLastError());
   if (e.m > 0 && e.z) {
     hipLaunchKernelGGL(post_reduce_kernel, dim3((unsigned)e.m), dim3(256), 0, s, e.vt, e.vt_ld, e.n, e.z,
-                       e.m_new, e.prior_diag, e.mean, e.var);
+                       e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var);
     GPX_HIP_CHECK(h, hipGetLastError());
   }
   return GPX_OK;

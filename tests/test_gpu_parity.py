@@ -99,6 +99,29 @@ def test_fused_fit_predict_matches_golden(core, name, lookahead):
     assert np.abs(mean2 - mean).max() <= 1e-10 * scale and np.abs(var2 - var).max() <= 1e-10
 
 
+def test_graph_replay_tracks_hyperparameters(core):
+    """The fused step is replayed from ONE captured hipGraph per shape; hyper-parameter values
+    live in device memory.  Replays with changing values must match the eager path and the oracle."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, y, xn, p = orc.synthetic_problem(300, 4, 21, seed=11)
+    core.set_option("nb", 128)
+    core.set_train(x)
+    core.set_test(xn)
+    for graph in (1, 0, 1):
+        core.set_option("graph", graph)
+        for scale, ell, noise in [(1.0, 1.0, 0.0067), (2.5, 0.6, 0.02), (0.7, np.array([0.5, 1.0, 1.5, 2.0]), 0.001)]:
+            q = dict(p, k_scale=np.array([scale]), k_length=np.atleast_1d(ell), k_noise=np.array([noise]))
+            prm = gpax_amd.make_params(0, q["k_scale"], q["k_length"], None, q["k_noise"], q["k_jitter"])
+            info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(21), noise)
+            logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, q, observation_noise=True)
+            assert info == 0
+            assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+            assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
+    core.set_option("graph", 1)
+
+
 def test_gram_edge_shapes(core):
     """Ragged / odd / rectangular shapes, d spanning the LDS chunk (16), the diagonal
     rule keyed on shapes (gpax/kernels.py:124), vector noise, empty inputs."""

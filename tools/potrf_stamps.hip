@@ -31,6 +31,7 @@ static void run(int nwaves_label) {
   hipDeviceSynchronize();
   unsigned long long st[64]; hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost);
   printf("NB=%d: load %llu cycles, first leaf %llu\n", NB, st[1] - st[0], st[2] - st[1]);
+  printf("  first leaf: wave0 (potrf) done after %llu cycles, wave1 (inverse) after %llu\n", st[40] - st[1], st[41] - st[1]);
   unsigned long long pa = 0, sh = 0;
   for (int jb = 0; jb < NT; ++jb) {
     unsigned long long a_ = st[3 + 2 * jb] - st[2 + 2 * jb], b_ = st[2 + 2 * (jb + 1)] - st[3 + 2 * jb];
