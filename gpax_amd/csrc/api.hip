@@ -84,6 +84,32 @@ static int prof_collect(gpx_handle* h) {
 
 extern "C" int gpx_abi_version(void) { return GPX_ABI_VERSION; }
 
+// Two streams: s_main carries the critical path (diagonal block, panel solve, look-ahead column)
+// at the highest priority; s_trail carries the bulk trailing updates at the lowest priority and,
+// optionally (GPX_TRAIL_CUS=n), on a CU mask that leaves 256-n CUs permanently free for s_main, so
+// a critical-path kernel never queues behind resident trailing-update workgroups.
+static hipError_t create_streams(gpx_handle* h) {
+  int lo = 0, hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
+  if (e != hipSuccess) return e;
+  if ((e = hipStreamCreateWithPriority(&h->s_main, hipStreamNonBlocking, hi)) != hipSuccess) return e;
+  const char* env = getenv("GPX_TRAIL_CUS");
+  const int ncu = h->prop.multiProcessorCount;
+  int keep = env ? atoi(env) : 0;
+  if (keep > 0 && keep < ncu) {
+    // spread the EXCLUDED CUs evenly over the chip (CU i sits on XCD i % 8 in the mask order)
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    const int drop = ncu - keep;
+    for (int i = 0; i < ncu; ++i) {
+      const bool excluded = ((int64_t)i * drop / ncu) != ((int64_t)(i + 1) * drop / ncu);
+      if (!excluded) mask[(size_t)i / 32] |= 1u << (i % 32);
+    }
+    e = hipExtStreamCreateWithCUMask(&h->s_trail, (uint32_t)mask.size(), mask.data());
+    if (e == hipSuccess) return e;
+  }
+  return hipStreamCreateWithPriority(&h->s_trail, hipStreamNonBlocking, lo);
+}
+
 extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if (!out) return GPX_ERR_ARG;
   *out = nullptr;
@@ -97,8 +123,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   gpx_handle* h = new gpx_handle();
   h->device = device_id;
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&h->prop, device_id)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&h->s_main, hipStreamNonBlocking)) != hipSuccess ||
-      (e = hipStreamCreateWithFlags(&h->s_trail, hipStreamNonBlocking)) != hipSuccess ||
+      (e = create_streams(h)) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&h->d_scal), 8 * sizeof(double))) != hipSuccess ||
       (e = hipMalloc(reinterpret_cast<void**>(&h->d_info), 4 * sizeof(int))) != hipSuccess) {
     g_create_error = std::string("gpx_create: ") + hipGetErrorString(e);
@@ -129,6 +154,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   for (auto e : h->ev_panel) (void)hipEventDestroy(e);
   for (auto e : h->ev_trail) (void)hipEventDestroy(e);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -321,6 +347,7 @@ extern "C" int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const dou
 // ------------------------------------------------------------- bordered factorisation
 
 static int ensure_events(gpx_handle* h, size_t nblk) {
+  if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
   while (h->ev_panel.size() < nblk) {
     hipEvent_t a, b;
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -362,7 +389,8 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
     GPX_RET(launch_gemm_nt(h, P, g));
     prof_end(h, P);
     if (k + 1 >= nblk) continue;
-    // look-ahead: column block k+1 (rows r0.., columns r0..r0+nb)
+    // look-ahead: column block k+1 (rows r0.., columns r0..r0+nb); last written by the previous
+    // trailing update on the other stream
     if (h->lookahead && k >= 1 && trail_pending[(size_t)(k - 1)])
       GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_trail[(size_t)(k - 1)], 0));
     GemmLaunch u;
@@ -381,21 +409,29 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
       GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], P));
       GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
     }
+    // Trailing update of everything right of the look-ahead column, on the second stream.  (Splitting
+    // it so that the next look-ahead only waits for its own column block was measured: no gain, the
+    // small critical-path GEMMs are starved of CUs while this kernel runs either way.)
     GemmLaunch t;
     t.A = L + r1 * ld + c0; t.lda = ld;
     t.B = L + r1 * ld + c0; t.ldb = ld;
     t.C = A + r1 * ld + r1; t.ldc = ld;
     t.M = mr; t.N = ncols; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
     t.lower = 1; t.row_off = r1; t.col_off = r1; t.b_lower_tri = 0; t.small_tile = 0;
-    // algorithmic work: the lower trapezoid of (mr x ncols) entries, 2*nb flop each
-    const double entries = (double)ncols * (ncols + 1) / 2.0 + (double)(mr - ncols) * ncols;
-    prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(mr + ncols) * nb));
-    GPX_RET(launch_gemm_nt(h, T, t));
-    prof_end(h, T);
+    {
+      const double entries = (double)ncols * (ncols + 1) / 2.0 + (double)(mr - ncols) * ncols;   // lower trapezoid, 2*nb flop each
+      prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(mr + ncols) * nb));
+      GPX_RET(launch_gemm_nt(h, T, t));
+      prof_end(h, T);
+    }
     if (h->lookahead) {
       GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
       trail_pending[(size_t)k] = 1;
     }
+  }
+  if (h->lookahead) {   // join: everything on T is done before anything later on P (epilogue, copies)
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
   }
   return GPX_OK;
 }

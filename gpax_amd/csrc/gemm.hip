@@ -125,6 +125,64 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
 }
 
+// ---- latency variant for K = nb (64 or 128): one pass, one barrier ---------------------------
+// The panel solve and the look-ahead update sit on the critical path of the factorisation and
+// are small (M x nb x nb), so what matters is the latency of ONE tile, not throughput: the whole
+// K range of the 32-row A and B tiles is fetched with every 16-B load of the workgroup in flight
+// at once (coalesced 256-B row segments), staged through LDS once, and each wave then runs its
+// K/4 MFMAs back to back on two accumulators (a dependent f64 MFMA issues every ~190 cycles, an
+// independent one every ~100).  One global round trip and one barrier per tile instead of K/32.
+// (A register-only variant with per-lane contiguous K chunks was tried and measured slower:
+// its loads touch 64 different cache lines per instruction.)
+template <int K>
+__global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
+  constexpr int LD = K + 2;                 // row stride 2 (mod 32) doubles: conflict-free fragment reads
+  constexpr int NCH = 32 * (K / 2) / 256;   // 16-B chunks per thread and operand
+  __shared__ __attribute__((aligned(16))) double As[32 * LD];
+  __shared__ __attribute__((aligned(16))) double Bs[32 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+  if (g.lower && (g.row_off + m0 + 31 < g.col_off + n0)) return;
+  const double* Ag = g.A + m0 * g.lda;
+  const double* Bg = g.B + n0 * g.ldb;
+  v2d ra[NCH], rb[NCH];
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int c = tid + it * 256;
+    ra[it] = *reinterpret_cast<const v2d*>(Ag + (int64_t)(c / (K / 2)) * g.lda + 2 * (c % (K / 2)));
+    rb[it] = *reinterpret_cast<const v2d*>(Bg + (int64_t)(c / (K / 2)) * g.ldb + 2 * (c % (K / 2)));
+  }
+  const int fr = lane & 15, fk = lane >> 4;
+  double* cp = g.C + (m0 + wm * 16 + fk) * g.ldc + n0 + wn * 16 + fr;   // row = fk + 4r, col = fr
+  v4d cin = {0.0, 0.0, 0.0, 0.0};
+  if (g.beta != 0.0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) cin[r] = cp[(int64_t)(4 * r) * g.ldc];
+  }
+#pragma unroll
+  for (int it = 0; it < NCH; ++it) {
+    const int c = tid + it * 256;
+    *reinterpret_cast<v2d*>(&As[(c / (K / 2)) * LD + 2 * (c % (K / 2))]) = ra[it];
+    *reinterpret_cast<v2d*>(&Bs[(c / (K / 2)) * LD + 2 * (c % (K / 2))]) = rb[it];
+  }
+  __syncthreads();
+  const double* Ap = &As[(wm * 16 + fr) * LD + fk];
+  const double* Bp = &Bs[(wn * 16 + fr) * LD + fk];
+  v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int s = 0; s < K / 4; s += 2) {
+    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s], Bp[4 * s], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s + 4], Bp[4 * s + 4], acc1, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double v = g.alpha * (acc0[r] + acc1[r]);
+    if (g.beta != 0.0) v += g.beta * cin[r];
+    cp[(int64_t)(4 * r) * g.ldc] = v;
+  }
+}
+
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   if (L.M <= 0 || L.N <= 0) return GPX_OK;
   const int bm = L.small_tile ? 32 : 64;
@@ -138,7 +196,9 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.M = L.M; g.N = L.N; g.K = L.K; g.alpha = L.alpha; g.beta = L.beta;
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
   dim3 grid((unsigned)(L.N / bm), (unsigned)(L.M / bm));
-  if (L.small_tile) hipLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, g);
+  if (L.small_tile && L.K == 128) hipLaunchKernelGGL((gemm_nt_onepass_kernel<128>), grid, dim3(256), 0, s, g);
+  else if (L.small_tile && L.K == 64) hipLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, g);
+  else if (L.small_tile) hipLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, g);
   else hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, s, g);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;

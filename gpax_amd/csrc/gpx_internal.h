@@ -158,6 +158,7 @@ struct gpx_handle {
 
   // events for the two-stream lookahead
   std::vector<hipEvent_t> ev_panel, ev_trail;
+  hipEvent_t ev_join = nullptr;
 
   // profiling
   int prof_mode = 0;
