@@ -70,6 +70,7 @@ SIGNATURES = {
     "gpx_log_marginal": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "gpx_posterior": (C.c_int, [C.c_void_p, _dp, C.c_double, _dp, _dp, _dp]),
     "gpx_prior_cov": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), C.c_double, _dp]),
+    "gpx_mvn_sample": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, _dp, C.c_int64, _dp]),
     "gpx_fit_predict": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), _dp, _dp, C.c_double, _dp, _dp, _dp]),
     "gpx_set_targets": (C.c_int, [C.c_void_p, _dp, _dp]),
     "gpx_fit_predict_async": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), C.c_double]),
@@ -155,6 +156,7 @@ class Core:
             raise GpxError(f"gpx_create({device_id}) failed ({ERR_NAMES.get(rc, rc)}): {msg}")
         self._h = h
         self.n = self.m = self.d = 0
+        self._gp_owner = self._gp_test = self._gp_factor = None  # bookkeeping of gpax_amd.gp
 
     # -- plumbing
     def close(self):
@@ -254,6 +256,18 @@ class Core:
         cov = np.empty((self.m, self.m))
         self._check(self._lib.gpx_prior_cov(self._h, C.byref(p), float(new_noise), _ptr(cov)), "gpx_prior_cov")
         return cov
+
+    def mvn_sample(self, mean, cov, eps):
+        """``mean + eps @ chol(cov).T`` on the device; eps (nsamp, m) standard-normal draws."""
+        cov = _arr(cov)
+        eps = _arr(eps)
+        m = cov.shape[0]
+        if cov.shape != (m, m) or eps.ndim != 2 or eps.shape[1] != m:
+            raise ValueError("cov must be (m,m), eps (nsamp,m)")
+        mean = _arr(mean).reshape(-1) if mean is not None else None
+        out = np.empty_like(eps)
+        info = self._check(self._lib.gpx_mvn_sample(self._h, _ptr(mean), _ptr(cov), m, _ptr(eps), eps.shape[0], _ptr(out)), "gpx_mvn_sample")
+        return info, out
 
     def fit_predict(self, params, y_minus_m, m_new=None, new_noise=0.0):
         p, _keep = params

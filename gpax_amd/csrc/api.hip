@@ -150,7 +150,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   (void)hipDeviceSynchronize();
   void* bufs[] = {h->d_x, h->d_xnew, h->d_r, h->d_mnew, h->d_hyp, h->d_noise, h->d_A, h->d_L, h->d_W,
                   h->d_S, h->d_cov, h->d_z, h->d_scal, h->d_info, h->d_mean, h->d_g1, h->d_g2,
-                  h->d_gout, h->d_vec};
+                  h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -717,6 +717,55 @@ extern "C" int gpx_prior_cov(gpx_handle* h, const gpx_kernel_params* p, double n
   GPX_HIP_CHECK(h, hipMemcpyAsync(cov_out, h->d_cov, (size_t)(m * m) * sizeof(double), hipMemcpyDeviceToHost, s));
   GPX_HIP_CHECK(h, hipStreamSynchronize(s));
   return GPX_OK;
+}
+
+// ------------------------------------------------------------------------ MVN sampling
+
+// dist.MultivariateNormal(mean, cov).sample(key, (n,)) of gpax/gp.py:335-337:  out = mean + eps L_c^T,
+// L_c = chol(cov).  The (m x m) Cholesky runs through the same blocked factorisation (its own
+// buffers: the cached GP factor stays valid); the draws eps ~ N(0, I) come from the caller.
+extern "C" int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* cov, int64_t m, const double* eps,
+                              int64_t nsamp, double* out) {
+  if (!h) return GPX_ERR_ARG;
+  if (!cov || !eps || !out || m <= 0 || nsamp <= 0) { gpx_set_error(h, "gpx_mvn_sample: bad argument"); return GPX_ERR_ARG; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  hipStream_t s = h->s_main;
+  const int64_t nb = h->nb, npad = round_up(m, nb), spad = round_up(nsamp, 64);
+  GPX_RET(ensure(h, &h->d_A2, &h->a2_cap, npad * npad));
+  GPX_RET(ensure(h, &h->d_L2, &h->l2_cap, npad * npad));
+  GPX_RET(ensure(h, &h->d_W2, &h->w2_cap, npad * nb));
+  GPX_RET(ensure(h, &h->d_S, &h->s_cap, 2 * spad * npad));
+  GPX_RET(ensure_events(h, (size_t)(npad / nb)));
+  GPX_HIP_CHECK(h, hipMemcpy2DAsync(h->d_A2, (size_t)npad * sizeof(double), cov, (size_t)m * sizeof(double),
+                                    (size_t)m * sizeof(double), (size_t)m, hipMemcpyHostToDevice, s));
+  GPX_RET(launch_fill_identity_pad(h, s, h->d_A2, npad, m, npad, npad));
+  GPX_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
+  // run the factor loop on the secondary buffers
+  std::swap(h->d_A, h->d_A2); std::swap(h->d_L, h->d_L2); std::swap(h->d_W, h->d_W2);
+  const int64_t sv_npad = h->npad, sv_ld = h->ld, sv_epad = h->epad;
+  h->npad = npad; h->ld = npad; h->epad = 0;
+  int rc = factor_loop(h, npad);
+  double* Lc = h->d_L;
+  h->npad = sv_npad; h->ld = sv_ld; h->epad = sv_epad;
+  std::swap(h->d_A, h->d_A2); std::swap(h->d_L, h->d_L2); std::swap(h->d_W, h->d_W2);
+  GPX_RET(rc);
+  double* E = h->d_S; double* Y = h->d_S + spad * npad;
+  GPX_HIP_CHECK(h, hipMemsetAsync(E, 0, (size_t)(spad * npad) * sizeof(double), s));
+  GPX_HIP_CHECK(h, hipMemcpy2DAsync(E, (size_t)npad * sizeof(double), eps, (size_t)m * sizeof(double),
+                                    (size_t)m * sizeof(double), (size_t)nsamp, hipMemcpyHostToDevice, s));
+  GemmLaunch g;
+  g.A = E; g.lda = npad; g.B = Lc; g.ldb = npad; g.C = Y; g.ldc = npad;
+  g.M = spad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0;
+  g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 0;
+  GPX_RET(launch_gemm_nt(h, s, g));
+  GPX_HIP_CHECK(h, hipMemcpy2DAsync(out, (size_t)m * sizeof(double), Y, (size_t)npad * sizeof(double),
+                                    (size_t)m * sizeof(double), (size_t)nsamp, hipMemcpyDeviceToHost, s));
+  int info = 0;
+  GPX_RET(read_info(h, &info));
+  if (mean)
+    for (int64_t r = 0; r < nsamp; ++r)
+      for (int64_t c = 0; c < m; ++c) out[r * m + c] += mean[c];
+  return info;
 }
 
 // ------------------------------------------------------------------ fused fit+predict

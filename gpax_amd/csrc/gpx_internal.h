@@ -146,6 +146,10 @@ struct gpx_handle {
   double* d_g2 = nullptr; int64_t g2_cap = 0;
   double* d_gout = nullptr; int64_t gout_cap = 0;
   double* d_vec = nullptr; int64_t vec_cap = 0;
+  // secondary factor buffers (Cholesky of the posterior covariance for MVN sampling)
+  double* d_A2 = nullptr; int64_t a2_cap = 0;
+  double* d_L2 = nullptr; int64_t l2_cap = 0;
+  double* d_W2 = nullptr; int64_t w2_cap = 0;
 
   // small outputs
   double* d_scal = nullptr;    // [0]=logdet [1]=quad

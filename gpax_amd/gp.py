@@ -1,0 +1,466 @@
+"""Gaussian-process model objects with gpax's Python surface (``gpax/gp.py``).
+
+Everything numeric on the hot path -- gram matrices, the Cholesky factor, the log-marginal
+likelihood, the posterior mean / covariance and the MVN draws -- runs in the HIP library through
+``gpax_amd._lib.Core`` (C ABI of ``include/gpx.h``).  What stays in host Python is what is plain
+Python in the reference too: transforms, mean functions, hyper-parameter bookkeeping and the
+HMC driver that calls the log-marginal.
+
+Deviations from the reference, on purpose:
+  * ``use_cholesky`` is accepted but the HIP path ALWAYS uses the Cholesky branch
+    (gpax/gp.py:295-301); the reference default is the explicit inverse (:303-310), which agrees
+    with it to ~cond(K)*eps (tests/test_oracle.py::test_golden_inverse_branch_gap_recorded).
+  * ``fit()`` uses a built-in HMC sampler with dual-averaging step-size adaptation in place of
+    NumPyro's NUTS (NumPyro/JAX are not part of this stack); the random streams differ from JAX's,
+    so agreement with the reference is statistical, not bitwise.
+"""
+
+from __future__ import annotations
+
+import math
+from copy import deepcopy
+
+import numpy as np
+
+from gpax_amd import _lib, state
+from gpax_amd.kernels import Kernel
+from gpax_amd.means import ConstantMean, Mean
+from gpax_amd.transforms import IdentityTransform, NormalizeTransform, ScaleTransform, Transform
+
+DATA_TYPES = (np.ndarray, type(None))
+Y_STD_DATA_TYPES = DATA_TYPES + (float, int)
+
+
+class GPSample:
+    """Container for GP results (gpax/gp.py:52-96)."""
+
+    def __init__(self, hp=None, y=None, mu=None, sd=None):
+        self._hp, self._y, self._mu, self._sd = hp, y, mu, sd
+
+    @property
+    def y(self):
+        """Samples over the GP, shape ``(hp, gp, L)``."""
+        return self._y
+
+    @property
+    def hp(self):
+        return self._hp
+
+    @property
+    def mu(self):
+        if self._y.shape[0] == 1:
+            return self._mu.squeeze()
+        return np.mean(self._y, axis=(0, 1)).squeeze()
+
+    @property
+    def sd(self):
+        if self._y.shape[0] == 1:
+            return self._sd.squeeze()
+        return np.std(self._y, axis=(0, 1)).squeeze()
+
+    @property
+    def ci(self):
+        return self.mu - 2.0 * self.sd, self.mu + 2.0 * self.sd
+
+
+class GaussianProcess:
+    """Core Gaussian process class (gpax/gp.py:99-501); same constructor keywords."""
+
+    def __init__(
+        self,
+        kernel,
+        x=None,
+        y=None,
+        y_std=None,
+        observation_noise=False,
+        hp_samples=100,
+        gp_samples=10,
+        input_transform="default",
+        output_transform="default",
+        metadata=None,
+        use_cholesky=False,
+        mean=None,
+    ):
+        if not isinstance(kernel, Kernel):
+            raise TypeError("kernel must be a gpax_amd.kernels.Kernel")
+        if not isinstance(x, DATA_TYPES) or not isinstance(y, DATA_TYPES):
+            raise TypeError("x and y must be numpy arrays or None")
+        if not isinstance(y_std, Y_STD_DATA_TYPES):
+            raise TypeError("y_std must be an array, a float, an int or None")
+        if not isinstance(observation_noise, bool) or not isinstance(use_cholesky, bool):
+            raise TypeError("observation_noise and use_cholesky must be bool")
+        for name, v in (("hp_samples", hp_samples), ("gp_samples", gp_samples)):
+            if not isinstance(v, int) or v <= 0:
+                raise ValueError(f"{name} must be a positive int")
+        self.kernel = kernel
+        self.x, self.y, self.y_std = x, y, y_std
+        self.observation_noise = observation_noise
+        self.hp_samples, self.gp_samples = hp_samples, gp_samples
+        self.input_transform = ScaleTransform() if input_transform == "default" else input_transform
+        self.output_transform = NormalizeTransform() if output_transform == "default" else output_transform
+        for t in (self.input_transform, self.output_transform):
+            if not isinstance(t, (Transform, type(None))):
+                raise TypeError("transforms must be Transform instances or None")
+        self.metadata = metadata if metadata is not None else {}
+        self.use_cholesky = use_cholesky
+        self.mean = mean if mean is not None else ConstantMean()
+        if not isinstance(self.mean, Mean):
+            raise TypeError("mean must be a gpax_amd.means.Mean")
+        self._is_fit = False
+        self._resident = None  # (id of x_transformed) currently resident in HBM
+        self._post_init()
+
+    # gpax/gp.py:171-193
+    def _post_init(self):
+        if self.x is None and self.y_std is not None:
+            raise ValueError("y_std cannot be set if no x or y data is given")
+        if self.y is not None and isinstance(self.y_std, (float, int)):
+            self.y_std = np.ones(self.y.shape) * self.y_std
+        if (self.y is None) ^ (self.x is None):
+            raise ValueError("x and y must either both be None or not")
+        if self.input_transform is None or self.x is None:
+            self.input_transform = IdentityTransform()
+        if self.output_transform is None or self.y is None:
+            self.output_transform = IdentityTransform()
+        self.input_transform.fit(self.x)
+        self.output_transform.fit(self.y)
+        self._class_specific_post_init()
+
+    def _class_specific_post_init(self):
+        pass
+
+    @property
+    def x_transformed(self):
+        return self.input_transform.forward(self.x, transforms_as="mean")
+
+    @property
+    def y_transformed(self):
+        y = self.output_transform.forward(self.y, transforms_as="mean")
+        return np.atleast_1d(y.squeeze())
+
+    @property
+    def y_std_transformed(self):
+        y_std = self.output_transform.forward(self.y_std, transforms_as="std")
+        if y_std is None:
+            return None
+        return np.atleast_1d(y_std.squeeze())
+
+    # ------------------------------------------------------------------ the HIP path
+    def _core(self):
+        return state.get_core()
+
+    def _make_train_resident(self):
+        """jax.device_put(x, state.device) of gpax/gp.py:527: once per model."""
+        core = self._core()
+        x = np.ascontiguousarray(self.x_transformed)
+        key = (id(self), x.shape)
+        if getattr(core, "_gp_owner", None) != key:
+            core.set_train(x)
+            core._gp_owner = key
+            core._gp_test = None
+            core._gp_factor = None
+        return core, x
+
+    def _kernel_struct(self, k_params, k_noise, k_jitter, x_rows):
+        kp = dict(k_params)
+        noise = np.asarray(k_noise, dtype=np.float64).reshape(-1)
+        if noise.size not in (1, x_rows):
+            raise ValueError("k_noise must be a scalar or one value per training point")
+        return _lib.make_params(
+            self.kernel.KIND, kp["k_scale"], kp["k_length"], kp.get("k_period"), noise, k_jitter, True
+        )
+
+    def _split(self, params):
+        params = deepcopy(params)
+        m_params = {k: v for k, v in params.items() if "m_" in k}  # substring filters, gpax/gp.py:230-231
+        k_params = {k: v for k, v in params.items() if "k_" in k}
+        k_noise = k_params.pop("k_noise")
+        k_jitter = k_params.pop("k_jitter")
+        return m_params, k_params, k_noise, k_jitter
+
+    def log_marginal(self, params):
+        """Log-density of the ``y_sampled`` site of ``_gp_prior`` (gpax/gp.py:145-151) at the data:
+        MVN(loc=m, covariance_matrix=k).log_prob(y).  As in the reference model, ``y_std`` is not
+        used here (only in prediction)."""
+        m_params, k_params, k_noise, k_jitter = self._split(params)
+        core, x = self._make_train_resident()
+        if core.m != 0:
+            core.set_test(np.zeros((0, x.shape[1])))
+            core._gp_test = None
+        core._gp_factor = None
+        r = self.y_transformed - self.mean(x, **m_params)
+        info, logp, _, _ = core.fit_predict(self._kernel_struct(k_params, k_noise, k_jitter, x.shape[0]), r, None, 0.0)
+        return logp if info == 0 else float("nan")
+
+    def _gp_prior(self, x=None, y=None, params=None, rng=None):
+        """The GP model of gpax/gp.py:133-151.  Without NumPyro there are no sample sites: with
+        ``y`` this returns the joint log-density (priors + MVN log-prob) at ``params`` (drawn from the
+        priors when omitted); without ``y`` it returns one draw of ``y_sampled`` from the prior."""
+        rng = rng if rng is not None else state.get_rng_key()[1]
+        if params is None:
+            params = {**self.mean.sample_parameters(rng), **self.kernel.sample_parameters(rng)}
+        if y is not None:
+            lp = self.log_marginal(params)
+            for name, p in {**self.mean._params, **self.kernel._params}.items():
+                if not p.is_constant:
+                    lp += float(np.sum(p.value.log_prob(params[name])))
+            return lp
+        x = self.x_transformed if x is None else np.asarray(x, dtype=np.float64)
+        m_params, k_params, k_noise, k_jitter = self._split(params)
+        mean = self.mean(x, **m_params)
+        cov = self.kernel(x, x, k_noise=k_noise, k_jitter=k_jitter, **k_params)
+        _, draw = self._core().mvn_sample(mean, cov, rng.standard_normal((1, x.shape[0])))
+        return draw[0]
+
+    def _get_mean_and_covariance_unconditioned(self, x_new, params):
+        """gpax/gp.py:212-245."""
+        m_params, k_params, k_noise, k_jitter = self._split(params)
+        mean = self.mean(x_new, **m_params)
+        noise = k_noise if self.observation_noise else 0.0
+        cov = self.kernel(x_new, x_new, k_noise=noise, k_jitter=k_jitter, **k_params)
+        return mean, cov
+
+    def _posterior(self, x_new, params, want_cov):
+        m_params, k_params, k_noise, k_jitter = self._split(params)
+        core, x = self._make_train_resident()
+        x_new = np.ascontiguousarray(np.asarray(x_new, dtype=np.float64))
+        test_key = (x_new.shape, hash(x_new.tobytes()))
+        if core._gp_test != test_key:
+            core.set_test(x_new)
+            core._gp_test = test_key
+        y_std = self.y_std_transformed
+        noise_train = y_std**2 if y_std is not None else k_noise  # gpax/gp.py:289-292
+        new_noise = float(np.asarray(k_noise).reshape(-1)[0]) if self.observation_noise else 0.0  # :283-286
+        prm = self._kernel_struct(k_params, noise_train, k_jitter, x.shape[0])
+        r = self.y_transformed - self.mean(x, **m_params)
+        m_new = np.broadcast_to(self.mean(x_new, **m_params), (x_new.shape[0],))
+        # The reference re-builds and re-factorises k_train on every call (gpax/gp.py:293-304); here the
+        # factor is cached on the device and reused while hyper-parameters and data are unchanged
+        # (e.g. the 100 candidate batches of AcquisitionFunction._optimize_halton).
+        fkey = hash((self.kernel.KIND, repr(sorted((k, np.asarray(v).tobytes()) for k, v in k_params.items())),
+                     np.asarray(noise_train).tobytes(), np.asarray(k_jitter).tobytes(), r.tobytes()))
+        if getattr(core, "_gp_factor", None) == (core._gp_owner, fkey):
+            _, mean, var, cov = core.posterior(m_new, new_noise, want_cov=want_cov)
+            return (mean, cov) if want_cov else (mean, var)
+        if not want_cov:
+            _, _, mean, var = core.fit_predict(prm, r, m_new, new_noise)
+            core._gp_factor = (core._gp_owner, fkey)
+            return mean, var
+        core.fit_factor(prm)
+        core.log_marginal(r)
+        core._gp_factor = (core._gp_owner, fkey)
+        _, mean, var, cov = core.posterior(m_new, new_noise, want_cov=True)
+        return mean, cov
+
+    def _get_mean_and_covariance(self, x_new, params):
+        """gpax/gp.py:247-312: posterior mean (M,) and covariance (M,M) at already-transformed
+        ``x_new`` for one hyper-parameter set."""
+        return self._posterior(x_new, params, want_cov=True)
+
+    # upstream (ziatdinovmax/gpax) name for the same thing
+    get_mvn_posterior = _get_mean_and_covariance
+
+    def _sample_gp_given_single_hp(self, rng, x_new, params, n, condition_on_data=True):
+        """gpax/gp.py:314-338."""
+        params = {**self._prior_constants(), **params}
+        if condition_on_data:
+            mean, cov = self._get_mean_and_covariance(x_new, params)
+        else:
+            mean, cov = self._get_mean_and_covariance_unconditioned(x_new, params)
+        mean = np.broadcast_to(mean, (x_new.shape[0],))
+        _, sampled = self._core().mvn_sample(mean, cov, rng.standard_normal((n, x_new.shape[0])))
+        return mean, np.sqrt(np.diagonal(cov)), sampled
+
+    def _prior_constants(self):
+        """Constants of the priors (e.g. k_jitter) as arrays of shape (plate,)."""
+        out = {}
+        for name, p in {**self.mean._params, **self.kernel._params}.items():
+            if p.is_constant:
+                out[name] = np.full((p.plate,), float(p.value))
+        return out
+
+    def _get_hp_samples_from_prior(self, rng, fast):
+        """gpax/gp.py:340-350."""
+        hp = {**self.mean.sample_parameters(rng, self.hp_samples), **self.kernel.sample_parameters(rng, self.hp_samples)}
+        n = self.hp_samples
+        if fast:
+            hp = {k: np.median(v, axis=0, keepdims=True) for k, v in hp.items()}
+            n = 1
+        return hp, n
+
+    def _get_hp_samples_from_posterior(self, fast):
+        raise NotImplementedError
+
+    def _sample_over_hps(self, rng, x_new, hp, n_hp, condition_on_data):
+        """The vmap over hyper-parameter draws of gpax/gp.py:352-391, as a loop: each draw is a
+        complete gram + factor + posterior on the GPU."""
+        mu, sd, ys = [], [], []
+        for i in range(n_hp):
+            p = {k: v[i] for k, v in hp.items()}
+            m, s, y = self._sample_gp_given_single_hp(rng, x_new, p, self.gp_samples, condition_on_data)
+            mu.append(m)
+            sd.append(s)
+            ys.append(y)
+        return hp, np.stack(mu), np.stack(sd), np.stack(ys)
+
+    def sample(self, x_new, fast=False):
+        """gpax/gp.py:399-462: returns a GPSample with ``y`` of shape (hp, gp, M)."""
+        x_new = self.input_transform.forward(x_new, transforms_as="mean")
+        _, rng = state.get_rng_key()
+        if self.x is None and self.y is None:
+            hp, n = self._get_hp_samples_from_prior(rng, fast)
+            hp, mu, sd, y = self._sample_over_hps(rng, x_new, hp, n, False)
+        elif not self._is_fit:
+            hp, n = self._get_hp_samples_from_prior(rng, fast)
+            hp, mu, sd, y = self._sample_over_hps(rng, x_new, hp, n, True)
+        else:
+            hp, n = self._get_hp_samples_from_posterior(fast)
+            hp, mu, sd, y = self._sample_over_hps(rng, x_new, hp, n, True)
+        hp = {k: np.atleast_1d(v) for k, v in hp.items()}
+        # transform back (gpax/gp.py:458-460; the (1,1) statistics broadcast over (hp, gp, M))
+        y = self.output_transform.reverse(y, transforms_as="mean")
+        mu = self.output_transform.reverse(mu, transforms_as="mean")
+        sd = self.output_transform.reverse(sd, transforms_as="std")
+        return GPSample(hp=hp, y=y, mu=mu, sd=sd)
+
+    def _fast_predict(self, rng, x_new):
+        """gpax/gp.py:464-484: median hyper-parameters -> posterior mean and sqrt(diag cov)."""
+        if self.x is None and self.y is None:
+            hps, _ = self._get_hp_samples_from_prior(rng, True)
+            condition = False
+        elif not self._is_fit:
+            hps, _ = self._get_hp_samples_from_prior(rng, True)
+            condition = True
+        else:
+            hps, _ = self._get_hp_samples_from_posterior(True)
+            condition = True
+        hps = {**self._prior_constants(), **{k: v[0] for k, v in hps.items()}}
+        if condition:
+            mu, var = self._posterior(x_new, hps, want_cov=False)  # only diag(cov) is used (:484)
+            return mu, np.sqrt(var)
+        mu, cov = self._get_mean_and_covariance_unconditioned(x_new, hps)
+        return np.broadcast_to(mu, (x_new.shape[0],)), np.sqrt(np.diagonal(cov))
+
+    def predict(self, x_new, fast=False):
+        """gpax/gp.py:486-501."""
+        if not fast:
+            sampled = self.sample(x_new, False)
+            return sampled.mu.squeeze(), sampled.sd.squeeze()
+        x_new = self.input_transform.forward(x_new, transforms_as="mean")
+        _, rng = state.get_rng_key()
+        mu, sd = self._fast_predict(rng, x_new)
+        mu = self.output_transform.reverse(mu, transforms_as="mean")
+        sd = self.output_transform.reverse(sd, transforms_as="std")
+        return mu.squeeze(), sd.squeeze()
+
+    def fit(self):
+        raise NotImplementedError
+
+
+class _ParamSpace:
+    """Bijection between the learnable hyper-parameters (non-constant Parameters, with plates)
+    and one unconstrained vector -- what NumPyro's NUTS samples in."""
+
+    def __init__(self, gp):
+        self.items = []
+        for name, p in {**gp.mean._params, **gp.kernel._params}.items():
+            if not p.is_constant:
+                self.items.append((name, p.value, p.plate))
+        self.dim = sum(pl for _, _, pl in self.items)
+        self.constants = gp._prior_constants()
+
+    def unpack(self, u):
+        params, log_jac, log_prior, o = dict(self.constants), 0.0, 0.0, 0
+        for name, dist, plate in self.items:
+            x, lj = dist.from_unconstrained(u[o : o + plate])
+            params[name] = np.asarray(x, dtype=np.float64)
+            log_jac += float(np.sum(lj))
+            log_prior += float(np.sum(dist.log_prob(x)))
+            o += plate
+        return params, log_prior + log_jac
+
+    def init_to_median(self):
+        return np.concatenate([np.atleast_1d(d.to_unconstrained(np.full(pl, d.median))) for _, d, pl in self.items])
+
+
+class ExactGP(GaussianProcess):
+    """gpax/gp.py:504-544: fully Bayesian GP; ``fit()`` samples the hyper-parameter posterior."""
+
+    def __init__(self, *args, mcmc=None, num_warmup=2000, num_chains=1, chain_method="sequential", mcmc_run_kwargs=None, **kw):
+        for name, v in (("num_warmup", num_warmup), ("num_chains", num_chains)):
+            if not isinstance(v, int) or v <= 0:
+                raise ValueError(f"{name} must be a positive int")
+        self.mcmc = mcmc
+        self.num_warmup, self.num_chains, self.chain_method = num_warmup, num_chains, chain_method
+        self.mcmc_run_kwargs = mcmc_run_kwargs if mcmc_run_kwargs is not None else {}
+        super().__init__(*args, **kw)
+
+    def _potential(self, space, u):
+        params, lp = space.unpack(u)
+        ll = self.log_marginal(params)
+        val = ll + lp
+        return val if np.isfinite(val) else -np.inf
+
+    def _grad(self, space, u, f0=None):
+        """Central differences in the unconstrained space (2*dim log-marginal evaluations, each a
+        complete GPU factorisation).  The analytic gradient needs K^-1: next."""
+        g = np.zeros_like(u)
+        for i in range(u.size):
+            h = 1e-5 * max(1.0, abs(u[i]))
+            up, um = u.copy(), u.copy()
+            up[i] += h
+            um[i] -= h
+            fp, fm = self._potential(space, up), self._potential(space, um)
+            g[i] = (fp - fm) / (2 * h) if np.isfinite(fp) and np.isfinite(fm) else 0.0
+        return g
+
+    def fit(self):
+        """Hamiltonian Monte Carlo over the hyper-parameters (gpax/gp.py:512-534: NUTS with
+        init_to_median, ``num_warmup`` adaptation steps, ``hp_samples`` kept draws per chain)."""
+        key, rng = state.get_rng_key()
+        space = _ParamSpace(self)
+        samples = {name: [] for name, _, _ in space.items}
+        n_leap = int(self.mcmc_run_kwargs.get("num_leapfrog", 8))
+        target_accept = float(self.mcmc_run_kwargs.get("target_accept_prob", 0.8))
+        for _ in range(self.num_chains):
+            u = space.init_to_median()
+            logp = self._potential(space, u)
+            grad = self._grad(space, u)
+            # dual averaging (Hoffman & Gelman 2014, alg. 5)
+            eps, mu_da, hbar, log_eps_bar, gamma, t0, kappa = 0.1, math.log(1.0), 0.0, 0.0, 0.05, 10.0, 0.75
+            for it in range(self.num_warmup + self.hp_samples):
+                p0 = rng.standard_normal(u.size)
+                un, pn, gn = u.copy(), p0 + 0.5 * eps * grad, grad
+                for s in range(n_leap):
+                    un = un + eps * pn
+                    gn = self._grad(space, un)
+                    pn = pn + (eps if s < n_leap - 1 else 0.5 * eps) * gn
+                logpn = self._potential(space, un)
+                log_alpha = (logpn - 0.5 * pn @ pn) - (logp - 0.5 * p0 @ p0)
+                alpha = min(1.0, math.exp(min(0.0, log_alpha))) if np.isfinite(log_alpha) else 0.0
+                if rng.uniform() < alpha:
+                    u, logp, grad = un, logpn, gn
+                if it < self.num_warmup:
+                    m = it + 1
+                    hbar = (1 - 1 / (m + t0)) * hbar + (target_accept - alpha) / (m + t0)
+                    log_eps = mu_da - math.sqrt(m) / gamma * hbar
+                    eta = m ** (-kappa)
+                    log_eps_bar = eta * log_eps + (1 - eta) * log_eps_bar
+                    eps = math.exp(log_eps)
+                    if m == self.num_warmup:
+                        eps = math.exp(log_eps_bar)
+                else:
+                    params, _ = space.unpack(u)
+                    for name, _, _ in space.items:
+                        samples[name].append(params[name])
+        self.mcmc = {k: np.stack(v) for k, v in samples.items()}
+        self.metadata["fit_key"] = np.array(key)
+        self._is_fit = True
+
+    def _get_hp_samples_from_posterior(self, fast):
+        """gpax/gp.py:536-544."""
+        hp = dict(self.mcmc)
+        if fast:
+            hp = {k: np.median(v, axis=0, keepdims=True) for k, v in hp.items()}
+        n = len(next(iter(hp.values())))
+        return hp, n

@@ -1,0 +1,36 @@
+"""Prior mean functions (``gpax/means.py``).  The mean vector is O(N) host work; it enters the HIP
+path as ``y - m(x)`` and ``m(x_new)``.  Learnable parameters start with ``"m_"``."""
+
+from __future__ import annotations
+
+import numpy as np
+
+from gpax_amd import state
+from gpax_amd.utils.prior_utils import Prior
+
+
+class Mean(Prior):
+    """gpax/means.py:27-63."""
+
+    attribute_prefix = "m_"
+
+    def _mean_function(self, x, **params):
+        raise NotImplementedError
+
+    def sample_prior(self, x, rng=None):
+        rng = rng if rng is not None else state.get_rng_key()[1]
+        return self.__call__(x, **self.sample_parameters(rng))
+
+    def __call__(self, x, **params):
+        # the mean function should always be 1-d (gpax/means.py:61-63)
+        return np.asarray(self._mean_function(x, **params), dtype=np.float64).squeeze()
+
+
+class ConstantMean(Mean):
+    """gpax/means.py:66-78; the default constant is 1.0, not 0 (gpax/means.py:75)."""
+
+    def __init__(self, mean=1.0):
+        self.mean = mean
+
+    def _mean_function(self, x):
+        return np.ones(np.asarray(x).shape[0]) * self.mean

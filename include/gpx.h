@@ -113,6 +113,13 @@ int gpx_posterior(gpx_handle* h, const double* m_new, double new_noise, double* 
  * cov = f(x_new, x_new, k_noise=new_noise, k_jitter) at the resident x_new. */
 int gpx_prior_cov(gpx_handle* h, const gpx_kernel_params* p, double new_noise, double* cov_out);
 
+/* dist.MultivariateNormal(mean, cov).sample(key, sample_shape=(n,))  (gpax/gp.py:335-337):
+ * out (nsamp,m) = mean + eps @ chol(cov)^T with the caller's standard-normal draws eps (nsamp,m)
+ * (JAX's threefry stream cannot be reproduced: statistical parity only).  cov (m,m); mean (m,) may be
+ * NULL.  Returns info > 0 (and NaNs) when cov is not positive definite, as numpyro would. */
+int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* cov, int64_t m, const double* eps,
+                   int64_t nsamp, double* out);
+
 /* One whole fit+predict step at one hyper-parameter setting -- the unit of the
  * benchmark metric and of _fast_predict (gpax/gp.py:464-484):
  * gram(x,x) + Cholesky + log-marginal + gram(x_new,x) + posterior mean/variance,
