@@ -294,14 +294,18 @@ class GaussianProcess:
     def _sample_over_hps(self, rng, x_new, hp, n_hp, condition_on_data):
         """The vmap over hyper-parameter draws of gpax/gp.py:352-391, as a loop: each draw is a
         complete gram + factor + posterior on the GPU."""
-        mu, sd, ys = [], [], []
-        for i in range(n_hp):
+        from gpax_amd import parallel
+
+        # one independent child stream per draw, so the result does not depend on how the draws
+        # are dealt over the ranks
+        seeds = rng.integers(0, 2**63 - 1, size=n_hp)
+
+        def one(i):
             p = {k: v[i] for k, v in hp.items()}
-            m, s, y = self._sample_gp_given_single_hp(rng, x_new, p, self.gp_samples, condition_on_data)
-            mu.append(m)
-            sd.append(s)
-            ys.append(y)
-        return hp, np.stack(mu), np.stack(sd), np.stack(ys)
+            return self._sample_gp_given_single_hp(np.random.default_rng(seeds[i]), x_new, p, self.gp_samples, condition_on_data)
+
+        mu, sd, ys = parallel.map_draws(one, n_hp)
+        return hp, mu, sd, ys
 
     def sample(self, x_new, fast=False):
         """gpax/gp.py:399-462: returns a GPSample with ``y`` of shape (hp, gp, M)."""

@@ -1,0 +1,80 @@
+"""Multi-GPU sharding of the path (one process per GPU, ``torch.distributed`` for the control plane).
+
+The reference has no distributed code at all (gpax/state.py:64 ``# TODO: multi-gpu support?``).  The
+path shards over INDEPENDENT units: gpax's ``vmap`` over hyper-parameter draws
+(gpax/gp.py:354-364, 384-390) -- each draw is a complete gram + factor + posterior with no
+interaction -- so draws are dealt round-robin over the ranks and there is NO collective on the data
+path; the only communication is the final gather of the small per-draw results (mu, sd, samples).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def world():
+    """(rank, world_size) of the active process group, (0, 1) without one."""
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def partition_draws(n_items, rank, world_size):
+    """Indices of the hyper-parameter draws rank ``rank`` owns: round-robin, so that every rank gets
+    ceil or floor of n/world draws whatever the order of the draws."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    return list(range(rank, n_items, world_size))
+
+
+def gather_draws(local, n_items, group=None):
+    """Reassemble per-draw results computed under ``partition_draws``.
+
+    ``local``: list of arrays (one per owned draw, all of one shape) on this rank.  Returns an array of
+    shape ``(n_items, *shape)`` in draw order on EVERY rank.  One ``all_gather`` of a padded buffer; on a
+    GPU node the backend may be "nccl" (= RCCL over xGMI), on CPU tests it is "gloo"."""
+    rank, ws = world()
+    if ws == 1:
+        return np.stack(local) if local else np.zeros((0,))
+    import torch
+    import torch.distributed as dist
+
+    per = (n_items + ws - 1) // ws
+    shape = None
+    if local:
+        shape = tuple(np.asarray(local[0]).shape)
+    shapes = [None] * ws
+    dist.all_gather_object(shapes, shape, group=group)
+    shape = next(s for s in shapes if s is not None)
+    buf = torch.zeros((per,) + shape, dtype=torch.float64)
+    for j, a in enumerate(local):
+        buf[j] = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64)))
+    out = [torch.zeros_like(buf) for _ in range(ws)]
+    dist.all_gather(out, buf, group=group)
+    full = np.zeros((n_items,) + shape)
+    for r in range(ws):
+        for j, idx in enumerate(partition_draws(n_items, r, ws)):
+            full[idx] = out[r][j].numpy()
+    return full
+
+
+def map_draws(fn, n_items, group=None):
+    """``[fn(i) for i in range(n_items)]`` with the draws sharded over the ranks; ``fn`` returns a tuple of
+    arrays.  Returns a tuple of stacked arrays, identical on every rank."""
+    rank, ws = world()
+    mine = [fn(i) for i in partition_draws(n_items, rank, ws)]
+    n_out = None
+    if mine:
+        n_out = len(mine[0])
+    if ws > 1:
+        import torch.distributed as dist
+
+        counts = [None] * ws
+        dist.all_gather_object(counts, n_out, group=group)
+        n_out = next(c for c in counts if c is not None)
+    return tuple(gather_draws([m[k] for m in mine], n_items, group) for k in range(n_out))
