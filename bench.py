@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet fp64 matrix (= vector) peak; tools/peaks measures the achievable rate
+FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet fp64 matrix (= vector) peak (the local guides list no fp64 MFMA figure)
+FP64_MFMA_MEASURED_TFLOPS = 49.3  # tools/peaks on this chip: v_mfma_f64_16x16x4_f64 issues every ~100 cycles/SIMD at 2.39 GHz (profiles/r01_peaks.txt)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -55,6 +56,18 @@ def hp_draw(rank):
         return 1.0, 1.0, k_noise
     rng = np.random.default_rng(1000 + rank)
     return float(np.exp(0.3 * rng.standard_normal())), float(np.exp(0.3 * rng.standard_normal())), k_noise
+
+
+def _committed_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected
+    in separate --pmc runs of this same command; profiles/r01_traffic.json), or None.  bench.py cannot
+    collect PMC counters itself."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -175,7 +188,9 @@ def main():
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": None,
+            "traffic": _committed_traffic("trailing_update"),
+            "peak_measured": FP64_MFMA_MEASURED_TFLOPS,
+            "frac_of_measured_peak": achieved / FP64_MFMA_MEASURED_TFLOPS,
             "launches_per_step": tr["launches"] / args.steps,
             "avg_launch_us": avg_s * 1e6,
             "algorithmic_flops_per_launch": flops_per_launch,
@@ -190,7 +205,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (g_bytes / g_avg * 1e-9 / HBM_PEAK_GBS) if g_avg > 0 else 0.0,
-            "traffic": None,
+            "traffic": _committed_traffic("gram"),
             "avg_launch_us": g_avg * 1e6,
         }
         out["stage_ms_per_step"] = {k: v["ms"] / args.steps for k, v in stages.items()}
