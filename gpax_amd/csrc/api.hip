@@ -140,6 +140,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_NB"))) h->nb = atoi(env) == 64 ? 64 : 128;
   if ((env = getenv("GPX_LOOKAHEAD"))) h->lookahead = atoi(env) != 0;
   if ((env = getenv("GPX_GRAPH"))) h->use_graph = atoi(env) != 0;
+  if ((env = getenv("GPX_TWO_STREAM_MIN_COLS"))) h->two_stream_min_cols = atoll(env);
   *out = h;
   return GPX_OK;
 }
@@ -189,6 +190,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "lookahead")) { h->lookahead = value != 0; return GPX_OK; }
   if (!strcmp(name, "graph")) { h->use_graph = value != 0; return GPX_OK; }
+  if (!strcmp(name, "two_stream_min_cols")) { h->two_stream_min_cols = value; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -198,6 +200,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "nb")) { *value = h->nb; return GPX_OK; }
   if (!strcmp(name, "lookahead")) { *value = h->lookahead; return GPX_OK; }
   if (!strcmp(name, "graph")) { *value = h->use_graph; return GPX_OK; }
+  if (!strcmp(name, "two_stream_min_cols")) { *value = h->two_stream_min_cols; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -389,9 +392,15 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
     GPX_RET(launch_gemm_nt(h, P, g));
     prof_end(h, P);
     if (k + 1 >= nblk) continue;
+    const int64_t ncols = npad - r0 - nb;            // columns right of the look-ahead block
+    const int64_t r1 = r0 + nb, mr = rows - r1;
+    // Trailing updates narrower than two_stream_min_cols would stay on the critical-path stream;
+    // measured at N=4096 the second stream pays at every size (0: 2.27, 1024: 2.31, 2048: 2.83 ms/step).
+    const bool two = h->lookahead && ncols >= h->two_stream_min_cols;
+    hipStream_t Tk = two ? T : P;
     // look-ahead: column block k+1 (rows r0.., columns r0..r0+nb); last written by the previous
-    // trailing update on the other stream
-    if (h->lookahead && k >= 1 && trail_pending[(size_t)(k - 1)])
+    // trailing update (other stream if that one ran there)
+    if (k >= 1 && trail_pending[(size_t)(k - 1)])
       GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_trail[(size_t)(k - 1)], 0));
     GemmLaunch u;
     u.A = L + r0 * ld + c0; u.lda = ld;
@@ -402,16 +411,13 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
     prof_begin(h, P, GPX_STAGE_TRAILING, 2.0 * (mrows - nb / 2.0) * nb * nb, 8.0 * (2.0 * mrows * nb + mrows * nb));
     GPX_RET(launch_gemm_nt(h, P, u));
     prof_end(h, P);
-    const int64_t ncols = npad - r0 - nb;
     if (ncols <= 0) continue;
-    const int64_t r1 = r0 + nb, mr = rows - r1;
-    if (h->lookahead) {
+    if (two) {   // after the look-ahead launch (measured: starting the big kernel under the look-ahead starves it: 2.54 vs 2.27 ms/step)
       GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], P));
       GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
     }
-    // Trailing update of everything right of the look-ahead column, on the second stream.  (Splitting
-    // it so that the next look-ahead only waits for its own column block was measured: no gain, the
-    // small critical-path GEMMs are starved of CUs while this kernel runs either way.)
+    // Trailing update of everything right of the look-ahead column (reads the panel, writes
+    // columns >= k+2 only).
     GemmLaunch t;
     t.A = L + r1 * ld + c0; t.lda = ld;
     t.B = L + r1 * ld + c0; t.ldb = ld;
@@ -420,11 +426,11 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
     t.lower = 1; t.row_off = r1; t.col_off = r1; t.b_lower_tri = 0; t.small_tile = 0;
     {
       const double entries = (double)ncols * (ncols + 1) / 2.0 + (double)(mr - ncols) * ncols;   // lower trapezoid, 2*nb flop each
-      prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(mr + ncols) * nb));
-      GPX_RET(launch_gemm_nt(h, T, t));
-      prof_end(h, T);
+      prof_begin(h, Tk, GPX_STAGE_TRAILING, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(mr + ncols) * nb));
+      GPX_RET(launch_gemm_nt(h, Tk, t));
+      prof_end(h, Tk);
     }
-    if (h->lookahead) {
+    if (two) {
       GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
       trail_pending[(size_t)k] = 1;
     }

@@ -48,11 +48,24 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     if (kk < kend) kend = kk;
   }
 
+  const int fr = lane & 15, fk = lane >> 4;
+  // The C tile is loaded FIRST, straight into the accumulators (its latency hides under the first
+  // A/B tile loads), pre-scaled so that the epilogue is a pure store:
+  //   beta*C + alpha*sum = alpha * (sum + (beta/alpha)*C)      (alpha = +-1 on every call site)
   v4d acc[TM][TN];
+  const double cscale = g.beta / g.alpha;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int j = 0; j < TN; ++j) {
+      if (g.beta != 0.0) {
+        const double* cp = g.C + (m0 + wm * (BM / 2) + i * 16 + fk) * g.ldc + n0 + wn * (BN / 2) + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = cscale * cp[(int64_t)(4 * r) * g.ldc];
+      } else {
+        acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
+      }
+    }
 
   v2d ra[NA], rb[NBc];
   const double* Ag = g.A + m0 * g.lda;
@@ -83,7 +96,6 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
   };
 
-  const int fr = lane & 15, fk = lane >> 4;
   const double* Ap = &As[(wm * (BM / 2) + fr) * GEMM_LDT + fk];
   const double* Bp = &Bs[(wn * (BN / 2) + fr) * GEMM_LDT + fk];
 
@@ -117,27 +129,152 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + wm * (BM / 2) + i * 16 + fk + 4 * r;
-        double* cp = g.C + row * g.ldc + col;
-        double v = g.alpha * acc[i][j][r];
-        if (g.beta != 0.0) v += g.beta * (*cp);
-        *cp = v;
+        g.C[row * g.ldc + col] = g.alpha * acc[i][j][r];
       }
     }
+}
+
+// ---- persistent, tile-pipelined variant of the 64x64 kernel (the trailing update) ------------
+// With K = nb = 128 a 64x64 tile is only four K-chunks of MFMA work, so in the plain kernel the
+// exposed first load and the C read-modify-write of every tile cost about a third of the time.
+// Here a workgroup walks a strided list of tiles and treats (tile, K-chunk) pairs as ONE flat
+// software pipeline: while chunk c of tile t is in the MFMAs the registers already hold the next
+// chunk -- of the same tile or of the next one -- and the next tile's C tile is fetched two
+// stages ahead into spare registers; the store of tile t overlaps the first chunk of tile t+1.
+// Tiles are enumerated over the lower trapezoid only (no empty workgroups).
+__global__ __launch_bounds__(256) void gemm_nt_persist_kernel(GemmArgs g, int ntj, int64_t ntiles) {
+  constexpr int BM = 64, BN = 64, TM = 2, TN = 2;
+  constexpr int NA = BM * (GEMM_BK / 2) / 256, NBc = BN * (GEMM_BK / 2) / 256;
+  __shared__ __attribute__((aligned(16))) double As[BM * GEMM_LDT];
+  __shared__ __attribute__((aligned(16))) double Bs[BN * GEMM_LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fk = lane >> 4;
+  const int nchunks = (int)(g.K / GEMM_BK);
+  const double cscale = g.beta / g.alpha;
+  const int64_t ntri = (int64_t)ntj * (ntj + 1) / 2;   // tiles in the triangular top part
+
+  auto decode = [&](int64_t t, int64_t& m0, int64_t& n0) {
+    int64_t ti, tj;
+    if (t < ntri) {   // row ti holds ti+1 tiles
+      ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while (ti * (ti + 1) / 2 > t) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+      tj = t - ti * (ti + 1) / 2;
+    } else {          // full rows below the square part
+      const int64_t u = t - ntri;
+      ti = ntj + u / ntj;
+      tj = u % ntj;
+    }
+    m0 = ti * BM; n0 = tj * BN;
+  };
+
+  v2d ra[NA], rb[NBc];
+  auto load_chunk = [&](int64_t m0, int64_t n0, int64_t k0) {
+    const double* Ag = g.A + m0 * g.lda + k0;
+    const double* Bg = g.B + n0 * g.ldb + k0;
+#pragma unroll
+    for (int it = 0; it < NA; ++it) {
+      const int c = tid + it * 256;
+      ra[it] = *reinterpret_cast<const v2d*>(Ag + (int64_t)(c >> 4) * g.lda + 2 * (c & 15));
+    }
+#pragma unroll
+    for (int it = 0; it < NBc; ++it) {
+      const int c = tid + it * 256;
+      rb[it] = *reinterpret_cast<const v2d*>(Bg + (int64_t)(c >> 4) * g.ldb + 2 * (c & 15));
+    }
+  };
+  v4d cnext[TM][TN];
+  auto load_c = [&](int64_t m0, int64_t n0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const double* cp = g.C + (m0 + wm * 32 + i * 16 + fk) * g.ldc + n0 + wn * 32 + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cnext[i][j][r] = cp[(int64_t)(4 * r) * g.ldc];
+      }
+  };
+
+  int64_t t = blockIdx.x;
+  if (t >= ntiles) return;
+  int64_t m0, n0, m1 = 0, n1 = 0;
+  decode(t, m0, n0);
+  load_chunk(m0, n0, 0);
+  load_c(m0, n0);
+  const double* Ap = &As[(wm * 32 + fr) * GEMM_LDT + fk];
+  const double* Bp = &Bs[(wn * 32 + fr) * GEMM_LDT + fk];
+  v4d acc[TM][TN];
+  for (; t < ntiles; t += gridDim.x) {
+    const int64_t tn = t + gridDim.x;
+    const bool has_next = tn < ntiles;
+    if (has_next) decode(tn, m1, n1);
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+      for (int it = 0; it < NA; ++it) {
+        const int q = tid + it * 256;
+        *reinterpret_cast<v2d*>(&As[(q >> 4) * GEMM_LDT + 2 * (q & 15)]) = ra[it];
+      }
+#pragma unroll
+      for (int it = 0; it < NBc; ++it) {
+        const int q = tid + it * 256;
+        *reinterpret_cast<v2d*>(&Bs[(q >> 4) * GEMM_LDT + 2 * (q & 15)]) = rb[it];
+      }
+      __syncthreads();
+      if (c + 1 < nchunks) load_chunk(m0, n0, (int64_t)(c + 1) * GEMM_BK);
+      else if (has_next) load_chunk(m1, n1, 0);
+      if (c == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = cscale * cnext[i][j];
+      }
+      if (c == 1 && has_next) load_c(m1, n1);   // cnext is free again from chunk 0 on
+#pragma unroll
+      for (int s = 0; s < GEMM_BK / 4; ++s) {
+        double a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = Ap[i * 16 * GEMM_LDT + 4 * s];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = Bp[j * 16 * GEMM_LDT + 4 * s];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        double* cp = g.C + (m0 + wm * 32 + i * 16 + fk) * g.ldc + n0 + wn * 32 + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * g.ldc] = g.alpha * acc[i][j][r];
+      }
+    m0 = m1; n0 = n1;
+  }
 }
 
 // ---- latency variant for K = nb (64 or 128): one pass, one barrier ---------------------------
 // The panel solve and the look-ahead update sit on the critical path of the factorisation and
 // are small (M x nb x nb), so what matters is the latency of ONE tile, not throughput: the whole
 // K range of the 32-row A and B tiles is fetched with every 16-B load of the workgroup in flight
-// at once (coalesced 256-B row segments), staged through LDS once, and each wave then runs its
-// K/4 MFMAs back to back on two accumulators (a dependent f64 MFMA issues every ~190 cycles, an
+// at once (coalesced row segments), staged through LDS in two halves, and each wave then runs its
+// K/4 MFMAs on two accumulators (a dependent f64 MFMA issues every ~190 cycles, an
 // independent one every ~100).  One global round trip and one barrier per tile instead of K/32.
 // (A register-only variant with per-lane contiguous K chunks was tried and measured slower:
 // its loads touch 64 different cache lines per instruction.)
 template <int K>
 __global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
-  constexpr int LD = K + 2;                 // row stride 2 (mod 32) doubles: conflict-free fragment reads
-  constexpr int NCH = 32 * (K / 2) / 256;   // 16-B chunks per thread and operand
+  // LDS holds HALF of K at a time (K/2 + 2 doubles per row; stride = 2 mod 32 doubles keeps the
+  // fragment reads conflict-free): 34 KB at K = 128, so four workgroups fit a CU and even the widest
+  // panel of the factorisation is resident in a single round.  All global loads of BOTH halves are in
+  // flight together; the second half waits in registers while the first is in the MFMAs.
+  constexpr int KH = K / 2;
+  constexpr int LD = KH + 2;
+  constexpr int NCH = 32 * (KH / 2) / 256;   // 16-B chunks per thread, operand and half
   __shared__ __attribute__((aligned(16))) double As[32 * LD];
   __shared__ __attribute__((aligned(16))) double Bs[32 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -146,13 +283,15 @@ __global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
   if (g.lower && (g.row_off + m0 + 31 < g.col_off + n0)) return;
   const double* Ag = g.A + m0 * g.lda;
   const double* Bg = g.B + n0 * g.ldb;
-  v2d ra[NCH], rb[NCH];
+  v2d ra[2][NCH], rb[2][NCH];
 #pragma unroll
-  for (int it = 0; it < NCH; ++it) {
-    const int c = tid + it * 256;
-    ra[it] = *reinterpret_cast<const v2d*>(Ag + (int64_t)(c / (K / 2)) * g.lda + 2 * (c % (K / 2)));
-    rb[it] = *reinterpret_cast<const v2d*>(Bg + (int64_t)(c / (K / 2)) * g.ldb + 2 * (c % (K / 2)));
-  }
+  for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = tid + it * 256;
+      ra[hf][it] = *reinterpret_cast<const v2d*>(Ag + (int64_t)(c / (KH / 2)) * g.lda + hf * KH + 2 * (c % (KH / 2)));
+      rb[hf][it] = *reinterpret_cast<const v2d*>(Bg + (int64_t)(c / (KH / 2)) * g.ldb + hf * KH + 2 * (c % (KH / 2)));
+    }
   const int fr = lane & 15, fk = lane >> 4;
   double* cp = g.C + (m0 + wm * 16 + fk) * g.ldc + n0 + wn * 16 + fr;   // row = fk + 4r, col = fr
   v4d cin = {0.0, 0.0, 0.0, 0.0};
@@ -160,20 +299,24 @@ __global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) cin[r] = cp[(int64_t)(4 * r) * g.ldc];
   }
-#pragma unroll
-  for (int it = 0; it < NCH; ++it) {
-    const int c = tid + it * 256;
-    *reinterpret_cast<v2d*>(&As[(c / (K / 2)) * LD + 2 * (c % (K / 2))]) = ra[it];
-    *reinterpret_cast<v2d*>(&Bs[(c / (K / 2)) * LD + 2 * (c % (K / 2))]) = rb[it];
-  }
-  __syncthreads();
   const double* Ap = &As[(wm * 16 + fr) * LD + fk];
   const double* Bp = &Bs[(wn * 16 + fr) * LD + fk];
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int s = 0; s < K / 4; s += 2) {
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s], Bp[4 * s], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s + 4], Bp[4 * s + 4], acc1, 0, 0, 0);
+  for (int hf = 0; hf < 2; ++hf) {
+    if (hf) __syncthreads();   // everyone is done reading the first half
+#pragma unroll
+    for (int it = 0; it < NCH; ++it) {
+      const int c = tid + it * 256;
+      *reinterpret_cast<v2d*>(&As[(c / (KH / 2)) * LD + 2 * (c % (KH / 2))]) = ra[hf][it];
+      *reinterpret_cast<v2d*>(&Bs[(c / (KH / 2)) * LD + 2 * (c % (KH / 2))]) = rb[hf][it];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KH / 4; s += 2) {
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s], Bp[4 * s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s + 4], Bp[4 * s + 4], acc1, 0, 0, 0);
+    }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -196,6 +339,16 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.M = L.M; g.N = L.N; g.K = L.K; g.alpha = L.alpha; g.beta = L.beta;
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
   dim3 grid((unsigned)(L.N / bm), (unsigned)(L.M / bm));
+  // the persistent pipelined kernel serves the lower-trapezoid updates with C accumulation
+  if (!L.small_tile && L.variant == 1 && L.lower && L.beta != 0.0 && L.row_off == L.col_off && L.M >= L.N && L.K >= 2 * GEMM_BK) {
+    const int64_t ntj = L.N / 64, nti = L.M / 64;
+    const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
+    const int64_t slots = 256 * 3;   // CUs x resident workgroups (140 VGPRs -> 3 waves/SIMD)
+    dim3 pg((unsigned)(ntiles < slots ? ntiles : slots));
+    hipLaunchKernelGGL(gemm_nt_persist_kernel, pg, dim3(256), 0, s, g, (int)ntj, ntiles);
+    GPX_HIP_CHECK(h, hipGetLastError());
+    return GPX_OK;
+  }
   if (L.small_tile && L.K == 128) hipLaunchKernelGGL((gemm_nt_onepass_kernel<128>), grid, dim3(256), 0, s, g);
   else if (L.small_tile && L.K == 64) hipLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, g);
   else if (L.small_tile) hipLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, g);

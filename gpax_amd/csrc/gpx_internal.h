@@ -66,6 +66,7 @@ struct GemmLaunch {
   int64_t row_off, col_off;
   int b_lower_tri;      // B is lower triangular (B[n][k] = 0 for k > n): skip dead K
   int small_tile;       // 1: 32x32 workgroup tiles (latency path), 0: 64x64 (throughput path)
+  int variant = 0;      // 64x64 path: 0 = one workgroup per tile, 1 = persistent tile-pipelined kernel
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
 
@@ -114,6 +115,7 @@ struct gpx_handle {
   // options
   int nb = 128;
   int lookahead = 1;
+  int64_t two_stream_min_cols = 0;  // trailing updates narrower than this stay on the critical-path stream
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
   // resident inputs
