@@ -77,6 +77,7 @@ SIGNATURES = {
     "gpx_fetch_results": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "gpx_profile_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "gpx_profile_reset": (C.c_int, [C.c_void_p]),
+    "gpx_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gpx_profile_get": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64), _dp, _dp]),
     "gpx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "gpx_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
@@ -304,6 +305,9 @@ class Core:
     # -- measurement
     def profile_mode(self, mode):
         self._check(self._lib.gpx_profile_mode(self._h, int(mode)), "gpx_profile_mode")
+
+    def profile_dump(self, path):
+        self._check(self._lib.gpx_profile_dump(self._h, str(path).encode()), "gpx_profile_dump")
 
     def profile_reset(self):
         self._check(self._lib.gpx_profile_reset(self._h), "gpx_profile_reset")

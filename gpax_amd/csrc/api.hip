@@ -3,6 +3,7 @@
 // solves against a cached factor, and the measurement hooks.
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -873,6 +874,28 @@ extern "C" int gpx_profile_mode(gpx_handle* h, int mode) {
   if (!h) return GPX_ERR_ARG;
   GPX_RET(prof_collect(h));
   h->prof_mode = mode;
+  return GPX_OK;
+}
+
+// Diagnostic: write (stage, stream, start_us, end_us) of every bracketed launch still pending
+// (i.e. since the last collect) to a CSV; times are relative to the first event.
+extern "C" int gpx_profile_dump(gpx_handle* h, const char* path) {
+  if (!h || !path) return GPX_ERR_ARG;
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_trail));
+  FILE* f = fopen(path, "w");
+  if (!f) { gpx_set_error(h, "gpx_profile_dump: cannot open file"); return GPX_ERR_ARG; }
+  fprintf(f, "stage,start_us,end_us\n");
+  if (!h->pending.empty()) {
+    hipEvent_t e0 = h->pending.front().a;
+    for (auto& p : h->pending) {
+      float a = 0.f, b = 0.f;
+      (void)hipEventElapsedTime(&a, e0, p.a);
+      (void)hipEventElapsedTime(&b, e0, p.b);
+      fprintf(f, "%d,%.2f,%.2f\n", p.stage, a * 1e3, b * 1e3);
+    }
+  }
+  fclose(f);
   return GPX_OK;
 }
 

@@ -346,6 +346,23 @@ __device__ __forceinline__ void leaf_winv(double* Wd, double* share, int lane, i
   }
 }
 
+// one wave writes LDS tile (ib, jb) of `tiles` to the global matrix `dst` (leading dimension ld);
+// for a diagonal tile of L the don't-care entries above the diagonal become zeros
+__device__ __forceinline__ void store_tile(const double* tiles, double* dst, int64_t ld, int ib, int jb, int lane,
+                                           bool zero_upper_of_diag) {
+  const int r = lane >> 2, c4 = (lane & 3) * 4;
+  const double* src = tiles + tix(ib, jb) * 256;
+  double* out = dst + (int64_t)(ib * 16 + r) * ld + jb * 16 + c4;
+  double v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = src[eix(r, c4 + q)];
+    if (zero_upper_of_diag && ib == jb && c4 + q > r) v[q] = 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) out[q] = v[q];
+}
+
 // Schedule (NT = NB/16 sub-panels; wave 0 carries the critical path):
 //   leaf(0) | for jb: phase A (sub-panel solve, all waves) | { wave 0: update tile (jb+1,jb+1),
 //   leaf(jb+1) }  ||  { other waves: the rest of the rank-16 update, then row jb of W }
@@ -367,44 +384,59 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
   GPX_STAMP(0);
   for (int t = tid; t < LEAF_SHARE_DOUBLES; t += NWAVES * 64) sh[t] = 0.0;   // epochs start at 0
 
-  // ---- load the lower tiles of A_kk: all global loads of a wave in flight, then the LDS writes
+  // ---- load the lower tiles of A_kk.  Wave 0 fetches only the first diagonal tile (all the first
+  // leaf needs), waves 2.. fetch the rest; every global load is issued BEFORE the barrier and the bulk
+  // of them lands while the first leaf is already running (plain loads stay in flight across
+  // s_barrier).  Wave 1 (the inverse half of the leaf) loads nothing.
+  constexpr int LW = NWAVES - 2;                         // loader waves
+  constexpr int TPL = (NTRI - 1 + LW - 1) / LW;          // tiles per loader wave
   {
     const int r = lane >> 2, c4 = (lane & 3) * 4;
-    double v[TPW][4];
+    double v[TPL][4];
+    if (wave == 0) {
+      const double* src = A + (int64_t)r * lda + c4;
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-      const int t = wave + u * NWAVES;
-      if (t < NTRI) {
-        int ib = 0, jb = t;
-        while (jb > ib) { jb -= ib + 1; ++ib; }
-        const double* src = A + (int64_t)(ib * 16 + r) * lda + jb * 16 + c4;
+      for (int q = 0; q < 4; ++q) v[0][q] = src[q];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[u][q] = src[q];
+      for (int q = 0; q < 4; ++q) Lt[eix(r, c4 + q)] = v[0][q];
+    } else if (wave >= 2) {
+#pragma unroll
+      for (int u = 0; u < TPL; ++u) {
+        const int t = 1 + (wave - 2) + u * LW;
+        if (t < NTRI) {
+          int ib = 0, jb = t;
+          while (jb > ib) { jb -= ib + 1; ++ib; }
+          const double* src = A + (int64_t)(ib * 16 + r) * lda + jb * 16 + c4;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[u][q] = src[q];
+        }
       }
     }
+    __syncthreads();   // hand-off area zeroed, tile (0,0) in LDS
+    GPX_STAMP(1);
+    if (wave == 0) { leaf_potrf(Lt + tix(0, 0) * 256, sh, lane, 0, info, col0); GPX_STAMP(40); }
+    else if (wave == 1) { leaf_winv(Wt + tix(0, 0) * 256, sh, lane, 0); GPX_STAMP_T(41, 64); }
+    else {
 #pragma unroll
-    for (int u = 0; u < TPW; ++u) {
-      const int t = wave + u * NWAVES;
-      if (t < NTRI) {
+      for (int u = 0; u < TPL; ++u) {
+        const int t = 1 + (wave - 2) + u * LW;
+        if (t < NTRI) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Lt[t * 256 + eix(r, c4 + q)] = v[u][q];
+          for (int q = 0; q < 4; ++q) Lt[t * 256 + eix(r, c4 + q)] = v[u][q];
+        }
       }
-    }
-    // zeros above the diagonal of the L block and of W (nothing depends on them)
-    for (int t = wave; t < NT * NT; t += NWAVES) {
-      const int ib = t / NT, jb = t % NT;
-      if (jb > ib) {
-        double* ldst = L + (int64_t)(ib * 16 + r) * ldl + jb * 16 + c4;
-        double* wdst = W + (int64_t)(ib * 16 + r) * NB + jb * 16 + c4;
+      // zeros above the diagonal of the L block and of W (nothing depends on them)
+      for (int t = wave - 2; t < NT * NT; t += LW) {
+        const int ib = t / NT, jb = t % NT;
+        if (jb > ib) {
+          double* ldst = L + (int64_t)(ib * 16 + r) * ldl + jb * 16 + c4;
+          double* wdst = W + (int64_t)(ib * 16 + r) * NB + jb * 16 + c4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { ldst[q] = 0.0; wdst[q] = 0.0; }
+          for (int q = 0; q < 4; ++q) { ldst[q] = 0.0; wdst[q] = 0.0; }
+        }
       }
     }
   }
-  __syncthreads();
-  GPX_STAMP(1);
-  if (wave == 0) { leaf_potrf(Lt + tix(0, 0) * 256, sh, lane, 0, info, col0); GPX_STAMP(40); }
-  else if (wave == 1) { leaf_winv(Wt + tix(0, 0) * 256, sh, lane, 0); GPX_STAMP_T(41, 64); }
   __syncthreads();
 
 #pragma unroll 1
@@ -439,6 +471,11 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
             tile_winv(Lt, Wt, jb, q - ntiles, fr, fk);   // row jb of W: off the critical path
           }
         }
+        // write out what is final: column jb of L (after phase A) and row jb-1 of W (previous slot)
+        for (int q = wave - 2; q < NT; q += NWAVES - 2) {
+          if (q < NT - jb) store_tile(Lt, L, ldl, jb + q, jb, lane, true);
+          else if (jb >= 1) store_tile(Wt, W, NB, jb - 1, q - (NT - jb), lane, false);
+        }
       }
     } else {
       // last row of W: nothing left to hide behind, all waves share it
@@ -448,24 +485,13 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
   }
 
   GPX_STAMP(2 + 2 * NT);
-  // ---- write L_kk (lower) and W_k (lower) tiles
+  // ---- write out the remainder: the last L tile and the last two rows of W (everything else went
+  // out in the shadow slots)
   {
-    const int r = lane >> 2, c4 = (lane & 3) * 4;
-    for (int t = wave; t < NTRI; t += NWAVES) {
-      int ib = 0, jb = t;
-      while (jb > ib) { jb -= ib + 1; ++ib; }
-      double* ldst = L + (int64_t)(ib * 16 + r) * ldl + jb * 16 + c4;
-      double* wdst = W + (int64_t)(ib * 16 + r) * NB + jb * 16 + c4;
-      const double* ls = Lt + t * 256;
-      const double* ws = Wt + t * 256;
-      double lv[4], wv[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        lv[q] = ls[eix(r, c4 + q)]; wv[q] = ws[eix(r, c4 + q)];
-        if (ib == jb && c4 + q > r) lv[q] = 0.0;   // the leaf leaves don't-care values above the diagonal
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { ldst[q] = lv[q]; wdst[q] = wv[q]; }
+    for (int q = wave; q < 2 * NT; q += NWAVES) {
+      if (q == 0) store_tile(Lt, L, ldl, NT - 1, NT - 1, lane, true);
+      else if (q <= NT) store_tile(Wt, W, NB, NT - 1, q - 1, lane, false);
+      else if (NT >= 2) store_tile(Wt, W, NB, NT - 2, q - NT - 1, lane, false);
     }
   }
   GPX_STAMP(3 + 2 * NT);

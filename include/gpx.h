@@ -150,6 +150,8 @@ int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, double* var
 /* mode 0 = off (default), 1 = bracket every launch of each stage with HIP events. */
 int gpx_profile_mode(gpx_handle* h, int mode);
 int gpx_profile_reset(gpx_handle* h);
+/* diagnostic: CSV (stage,start_us,end_us) of the bracketed launches since the last reset/get */
+int gpx_profile_dump(gpx_handle* h, const char* path);
 /* total milliseconds, number of launches and algorithmic flops+bytes summed over them. */
 int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launches,
                     double* flops, double* bytes);
