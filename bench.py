@@ -99,6 +99,8 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    if os.environ.get("GPX_BENCH_ONE_DEVICE"):  # rehearsal of the multi-rank plumbing on a one-GPU box only
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     import gpax_amd  # raises if libgpx_hip.so is missing: no fallback
@@ -175,7 +177,7 @@ def main():
             step()
         sync()
         prof_ms_per_step = (time.perf_counter() - t1) / args.steps * 1e3
-        stages = {gpax_amd._lib.STAGE_NAMES[i]: core.profile_get(i) for i in range(7)}
+        stages = {gpax_amd._lib.STAGE_NAMES[i]: core.profile_get(i) for i in range(8)}
         core.profile_mode(0)
         tr = stages["trailing_update"]
         avg_s = tr["ms"] * 1e-3 / max(tr["launches"], 1)

@@ -14,8 +14,8 @@ import numpy as np
 
 RBF, MATERN52, PERIODIC = 0, 1, 2
 
-STAGE_GRAM, STAGE_GRAM_CROSS, STAGE_POTRF_DIAG, STAGE_TRSM_PANEL, STAGE_TRAILING, STAGE_EPILOGUE, STAGE_FACTOR_TOTAL = range(7)
-STAGE_NAMES = ["gram", "gram_cross", "potrf_diag", "trsm_panel", "trailing_update", "epilogue", "factor_total"]
+STAGE_GRAM, STAGE_GRAM_CROSS, STAGE_POTRF_DIAG, STAGE_TRSM_PANEL, STAGE_TRAILING, STAGE_EPILOGUE, STAGE_FACTOR_TOTAL, STAGE_LOOKAHEAD = range(8)
+STAGE_NAMES = ["gram", "gram_cross", "potrf_diag", "trsm_panel", "trailing_update", "epilogue", "factor_total", "lookahead_update"]
 
 ERR_NAMES = {
     -1: "GPX_ERR_ARG",

@@ -70,6 +70,7 @@ static int prof_collect(gpx_handle* h) {
   if (h->pending.empty()) return GPX_OK;
   GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
   GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_trail));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_far));
   for (auto& p : h->pending) {
     float ms = 0.f;
     GPX_HIP_CHECK(h, hipEventElapsedTime(&ms, p.a, p.b));
@@ -85,29 +86,32 @@ static int prof_collect(gpx_handle* h) {
 
 extern "C" int gpx_abi_version(void) { return GPX_ABI_VERSION; }
 
-// Two streams: s_main carries the critical path (diagonal block, panel solve, look-ahead column)
-// at the highest priority; s_trail carries the bulk trailing updates at the lowest priority and,
-// optionally (GPX_TRAIL_CUS=n), on a CU mask that leaves 256-n CUs permanently free for s_main, so
-// a critical-path kernel never queues behind resident trailing-update workgroups.
+// Three streams.  s_main carries the critical path (diagonal block, panel solve, near look-ahead) at
+// the highest priority on all CUs.  s_far (far look-ahead) and s_trail (bulk trailing update) may be
+// put on a CU mask that leaves GPX_RESERVED_CUS CUs untouched (default 0 = no mask: measured no gain
+// once the bulk kernel is released only after the near look-ahead has been queued, see factor_loop).
 static hipError_t create_streams(gpx_handle* h) {
   int lo = 0, hi = 0;
   hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
   if (e != hipSuccess) return e;
   if ((e = hipStreamCreateWithPriority(&h->s_main, hipStreamNonBlocking, hi)) != hipSuccess) return e;
-  const char* env = getenv("GPX_TRAIL_CUS");
+  const char* env = getenv("GPX_RESERVED_CUS");
   const int ncu = h->prop.multiProcessorCount;
-  int keep = env ? atoi(env) : 0;
-  if (keep > 0 && keep < ncu) {
-    // spread the EXCLUDED CUs evenly over the chip (CU i sits on XCD i % 8 in the mask order)
+  int drop = env ? atoi(env) : 0;   // measured: no gain once the bulk kernel is released after the near look-ahead
+  if (drop > 0 && drop < ncu) {
+    // spread the EXCLUDED CUs evenly over the mask order
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    const int drop = ncu - keep;
     for (int i = 0; i < ncu; ++i) {
       const bool excluded = ((int64_t)i * drop / ncu) != ((int64_t)(i + 1) * drop / ncu);
       if (!excluded) mask[(size_t)i / 32] |= 1u << (i % 32);
     }
-    e = hipExtStreamCreateWithCUMask(&h->s_trail, (uint32_t)mask.size(), mask.data());
-    if (e == hipSuccess) return e;
+    hipError_t e1 = hipExtStreamCreateWithCUMask(&h->s_trail, (uint32_t)mask.size(), mask.data());
+    hipError_t e2 = hipExtStreamCreateWithCUMask(&h->s_far, (uint32_t)mask.size(), mask.data());
+    if (e1 == hipSuccess && e2 == hipSuccess) return hipSuccess;
+    if (e1 == hipSuccess) { (void)hipStreamDestroy(h->s_trail); h->s_trail = nullptr; }
+    if (e2 == hipSuccess) { (void)hipStreamDestroy(h->s_far); h->s_far = nullptr; }
   }
+  if ((e = hipStreamCreateWithPriority(&h->s_far, hipStreamNonBlocking, hi)) != hipSuccess) return e;
   return hipStreamCreateWithPriority(&h->s_trail, hipStreamNonBlocking, lo);
 }
 
@@ -141,7 +145,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_NB"))) h->nb = atoi(env) == 64 ? 64 : 128;
   if ((env = getenv("GPX_LOOKAHEAD"))) h->lookahead = atoi(env) != 0;
   if ((env = getenv("GPX_GRAPH"))) h->use_graph = atoi(env) != 0;
-  if ((env = getenv("GPX_TWO_STREAM_MIN_COLS"))) h->two_stream_min_cols = atoll(env);
+  if ((env = getenv("GPX_DEPTH"))) h->depth = atoi(env) >= 2 ? 2 : 1;
   *out = h;
   return GPX_OK;
 }
@@ -157,12 +161,15 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
+  for (auto e : h->ev_far) (void)hipEventDestroy(e);
   for (auto e : h->ev_panel) (void)hipEventDestroy(e);
   for (auto e : h->ev_trail) (void)hipEventDestroy(e);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (h->s_main) (void)hipStreamDestroy(h->s_main);
   if (h->s_trail) (void)hipStreamDestroy(h->s_trail);
+  if (h->s_far) (void)hipStreamDestroy(h->s_far);
   delete h;
   return GPX_OK;
 }
@@ -179,6 +186,7 @@ extern "C" int gpx_synchronize(gpx_handle* h) {
   if (!h) return GPX_ERR_ARG;
   GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
   GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_trail));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_far));
   return GPX_OK;
 }
 
@@ -191,7 +199,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "lookahead")) { h->lookahead = value != 0; return GPX_OK; }
   if (!strcmp(name, "graph")) { h->use_graph = value != 0; return GPX_OK; }
-  if (!strcmp(name, "two_stream_min_cols")) { h->two_stream_min_cols = value; return GPX_OK; }
+  if (!strcmp(name, "depth")) { h->depth = value >= 2 ? 2 : 1; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -201,7 +209,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "nb")) { *value = h->nb; return GPX_OK; }
   if (!strcmp(name, "lookahead")) { *value = h->lookahead; return GPX_OK; }
   if (!strcmp(name, "graph")) { *value = h->use_graph; return GPX_OK; }
-  if (!strcmp(name, "two_stream_min_cols")) { *value = h->two_stream_min_cols; return GPX_OK; }
+  if (!strcmp(name, "depth")) { *value = h->depth; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -352,6 +360,12 @@ extern "C" int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const dou
 
 static int ensure_events(gpx_handle* h, size_t nblk) {
   if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+  while (h->ev_far.size() < nblk) {
+    hipEvent_t a;
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    h->ev_far.push_back(a);
+  }
   while (h->ev_panel.size() < nblk) {
     hipEvent_t a, b;
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -364,17 +378,44 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
 
 // Right-looking blocked Cholesky of the (npad x npad) matrix in d_A with `rows - npad`
 // border rows riding along (they are only ever "rows below the panel").  Results in d_L.
-//   step k:  potrf_diag  A_kk -> L_kk, W_k = inv(L_kk)            (one workgroup, LDS resident)
-//            panel       L_ik = A_ik W_k^T      for all rows below  (MFMA GEMM)
-//            look-ahead  column block k+1 of the trailing matrix   (MFMA GEMM, same stream)
-//            trailing    the rest of the trailing matrix           (MFMA GEMM, second stream)
-// so the next panel overlaps the bulk of this step's trailing update.
+//   step k:  potrf_diag  A_kk -> L_kk, W_k = inv(L_kk)            (one workgroup, LDS resident)   stream P
+//            panel       L_ik = A_ik W_k^T      for all rows below  (MFMA GEMM)                    stream P
+//            near look-ahead  column block k+1 -= panel k           (MFMA GEMM)                    stream P
+//            far look-ahead   column blocks k+2 .. k+D              (MFMA GEMM)                    stream Q
+//            bulk update      column blocks >= k+D+1                (MFMA GEMM)                    stream T
+// P carries the critical path potrf -> panel -> near look-ahead and never waits for the bulk update of
+// the SAME step: with depth D = 2 column k+2 is brought up to date by Q one step early, so the only
+// thing P waits for is Q's short kernel of the previous step, which in turn had a whole step of slack
+// behind the bulk update it depends on.  Every column block has exactly one writer stream at a time
+// (T up to panel c-D-1, then Q, then P), each hand-over ordered by an event: no concurrent
+// read-modify-write of a tile.  D = 1 is the classic single look-ahead (P waits for the previous bulk
+// update); lookahead = 0 runs everything on P.
 static int factor_loop(gpx_handle* h, int64_t rows) {
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld;
   const int64_t nblk = npad / nb;
-  hipStream_t P = h->s_main, T = h->lookahead ? h->s_trail : h->s_main;
+  const bool la = h->lookahead != 0;
+  const int D = la ? (h->depth >= 2 ? 2 : 1) : 1;
+  hipStream_t P = h->s_main, T = la ? h->s_trail : h->s_main, Q = (la && D >= 2) ? h->s_far : h->s_main;
   double* A = h->d_A; double* L = h->d_L;
-  std::vector<char> trail_pending((size_t)nblk, 0);
+  std::vector<char> trail_pending((size_t)nblk, 0), far_pending((size_t)nblk, 0);
+
+  auto update = [&](hipStream_t st, int64_t k, int64_t cfirst, int64_t ncolblk, bool small) -> int {
+    // columns [cfirst, cfirst + ncolblk) blocks, rows from block row cfirst down, -= panel k
+    const int64_t c0 = k * nb, rr = cfirst * nb, mr = rows - rr, nc = ncolblk * nb;
+    GemmLaunch t;
+    t.A = L + rr * ld + c0; t.lda = ld;
+    t.B = L + rr * ld + c0; t.ldb = ld;
+    t.C = A + rr * ld + rr; t.ldc = ld;
+    t.M = mr; t.N = nc; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
+    t.lower = 1; t.row_off = rr; t.col_off = rr; t.b_lower_tri = 0; t.small_tile = small ? 1 : 0;
+    const double entries = (double)nc * (nc + 1) / 2.0 + (double)(mr - nc) * nc;   // lower trapezoid, 2*nb flop each
+    prof_begin(h, st, small ? GPX_STAGE_LOOKAHEAD : GPX_STAGE_TRAILING, 2.0 * entries * nb,
+               8.0 * (2.0 * entries + (double)(mr + nc) * nb));
+    int rc = launch_gemm_nt(h, st, t);
+    prof_end(h, st);
+    return rc;
+  };
+
   for (int64_t k = 0; k < nblk; ++k) {
     const int64_t c0 = k * nb, r0 = c0 + nb;
     prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
@@ -393,52 +434,43 @@ static int factor_loop(gpx_handle* h, int64_t rows) {
     GPX_RET(launch_gemm_nt(h, P, g));
     prof_end(h, P);
     if (k + 1 >= nblk) continue;
-    const int64_t ncols = npad - r0 - nb;            // columns right of the look-ahead block
-    const int64_t r1 = r0 + nb, mr = rows - r1;
-    // Trailing updates narrower than two_stream_min_cols would stay on the critical-path stream;
-    // measured at N=4096 the second stream pays at every size (0: 2.27, 1024: 2.31, 2048: 2.83 ms/step).
-    const bool two = h->lookahead && ncols >= h->two_stream_min_cols;
-    hipStream_t Tk = two ? T : P;
-    // look-ahead: column block k+1 (rows r0.., columns r0..r0+nb); last written by the previous
-    // trailing update (other stream if that one ran there)
-    if (k >= 1 && trail_pending[(size_t)(k - 1)])
-      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_trail[(size_t)(k - 1)], 0));
-    GemmLaunch u;
-    u.A = L + r0 * ld + c0; u.lda = ld;
-    u.B = L + r0 * ld + c0; u.ldb = ld;
-    u.C = A + r0 * ld + r0; u.ldc = ld;
-    u.M = mrows; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
-    u.lower = 1; u.row_off = r0; u.col_off = r0; u.b_lower_tri = 0; u.small_tile = 1;
-    prof_begin(h, P, GPX_STAGE_TRAILING, 2.0 * (mrows - nb / 2.0) * nb * nb, 8.0 * (2.0 * mrows * nb + mrows * nb));
-    GPX_RET(launch_gemm_nt(h, P, u));
-    prof_end(h, P);
-    if (ncols <= 0) continue;
-    if (two) {   // after the look-ahead launch (measured: starting the big kernel under the look-ahead starves it: 2.54 vs 2.27 ms/step)
-      GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], P));
-      GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
+    const int64_t nfar = std::min<int64_t>(D - 1, nblk - (k + 2));       // column blocks k+2 .. k+D
+    const int64_t nbulk = nblk - (k + 1 + D);                            // column blocks >= k+D+1
+    // near look-ahead (P): column k+1.  Its previous writer was Q (depth 2) or T (depth 1) at step k-1.
+    if (la && k >= 1) {
+      if (D >= 2 && far_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
+      if (D == 1 && trail_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_trail[(size_t)(k - 1)], 0));
     }
-    // Trailing update of everything right of the look-ahead column (reads the panel, writes
-    // columns >= k+2 only).
-    GemmLaunch t;
-    t.A = L + r1 * ld + c0; t.lda = ld;
-    t.B = L + r1 * ld + c0; t.ldb = ld;
-    t.C = A + r1 * ld + r1; t.ldc = ld;
-    t.M = mr; t.N = ncols; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
-    t.lower = 1; t.row_off = r1; t.col_off = r1; t.b_lower_tri = 0; t.small_tile = 0;
-    {
-      const double entries = (double)ncols * (ncols + 1) / 2.0 + (double)(mr - ncols) * ncols;   // lower trapezoid, 2*nb flop each
-      prof_begin(h, Tk, GPX_STAGE_TRAILING, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(mr + ncols) * nb));
-      GPX_RET(launch_gemm_nt(h, Tk, t));
-      prof_end(h, Tk);
+    GPX_RET(update(P, k, k + 1, 1, true));
+    // The other streams are released only now, after the near look-ahead is queued: the next
+    // diagonal-block kernel is ONE workgroup that needs a whole CU's LDS, and if the bulk kernel were
+    // already resident everywhere it would sit in the dispatcher until that kernel drains (measured:
+    // 37 -> 80 us per panel when the bulk update is released right after the panel solve).
+    if (la && (nfar > 0 || nbulk > 0)) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], P));
+
+    // far look-ahead (Q): columns k+2 .. k+D; column k+D was last written by the bulk update of step k-1
+    if (nfar > 0) {
+      if (la) {
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_panel[(size_t)k], 0));
+        if (k >= 1 && trail_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)(k - 1)], 0));
+      }
+      GPX_RET(update(Q, k, k + 2, nfar, true));
+      if (la) { GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q)); far_pending[(size_t)k] = 1; }
     }
-    if (two) {
-      GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
-      trail_pending[(size_t)k] = 1;
+    // bulk update (T): everything right of the look-ahead columns
+    if (nbulk > 0) {
+      if (la) GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
+      GPX_RET(update(T, k, k + 1 + D, nbulk, false));
+      if (la) { GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T)); trail_pending[(size_t)k] = 1; }
     }
   }
-  if (h->lookahead) {   // join: everything on T is done before anything later on P (epilogue, copies)
+  if (la) {   // join: everything on T and Q is done before anything later on P (epilogue, copies)
     GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
     GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
+    if (Q != P) {
+      GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join2, 0));
+    }
   }
   return GPX_OK;
 }
@@ -810,7 +842,7 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
     // d_hyp / d_noise / d_r / d_mnew, so the same graph is replayed for every hyper-parameter draw.
     char key[512];
     snprintf(key, sizeof(key), "%d|%d|%lld|%lld|%d|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p", fp.kind, fp.apply_noise,
-             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
+             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
              (void*)h->d_x, (void*)h->d_xnew, (void*)h->d_r, (void*)(h->have_mnew ? h->d_mnew : nullptr),
              (void*)h->d_hyp, (void*)fp.noise_dev, (void*)h->d_mean, (void*)h->d_z);
     auto it = h->graphs.find(key);
@@ -883,6 +915,7 @@ extern "C" int gpx_profile_dump(gpx_handle* h, const char* path) {
   if (!h || !path) return GPX_ERR_ARG;
   GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
   GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_trail));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_far));
   FILE* f = fopen(path, "w");
   if (!f) { gpx_set_error(h, "gpx_profile_dump: cannot open file"); return GPX_ERR_ARG; }
   fprintf(f, "stage,start_us,end_us\n");

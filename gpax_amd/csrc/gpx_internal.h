@@ -108,14 +108,14 @@ struct StageProf {
 
 struct gpx_handle {
   int device = 0;
-  hipStream_t s_main = nullptr, s_trail = nullptr;
+  hipStream_t s_main = nullptr, s_trail = nullptr, s_far = nullptr;
   std::string err;
   hipDeviceProp_t prop;
 
   // options
   int nb = 128;
   int lookahead = 1;
-  int64_t two_stream_min_cols = 0;  // trailing updates narrower than this stay on the critical-path stream
+  int depth = 2;       // look-ahead depth: 1 = classic, 2 = far look-ahead column on a third stream
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
   // resident inputs
@@ -164,7 +164,8 @@ struct gpx_handle {
 
   // events for the two-stream lookahead
   std::vector<hipEvent_t> ev_panel, ev_trail;
-  hipEvent_t ev_join = nullptr;
+  hipEvent_t ev_join = nullptr, ev_join2 = nullptr;
+  std::vector<hipEvent_t> ev_far;
 
   // profiling
   int prof_mode = 0;

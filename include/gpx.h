@@ -143,10 +143,11 @@ int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, double* var
 #define GPX_STAGE_GRAM_CROSS 1  /* gram build of k_cross (m x n) */
 #define GPX_STAGE_POTRF_DIAG 2  /* LDS-resident diagonal-block factorisation */
 #define GPX_STAGE_TRSM_PANEL 3  /* panel solve as MFMA GEMM against inv(L_kk) */
-#define GPX_STAGE_TRAILING 4    /* trailing SYRK/GEMM update on fp64 MFMA */
+#define GPX_STAGE_TRAILING 4    /* bulk trailing SYRK/GEMM update on fp64 MFMA (the dominant kernel) */
 #define GPX_STAGE_EPILOGUE 5    /* log-det / quadratic form / mean / variance reductions */
 #define GPX_STAGE_FACTOR_TOTAL 6
-#define GPX_N_STAGES 7
+#define GPX_STAGE_LOOKAHEAD 7   /* near / far look-ahead column updates (small latency-path GEMMs) */
+#define GPX_N_STAGES 8
 /* mode 0 = off (default), 1 = bracket every launch of each stage with HIP events. */
 int gpx_profile_mode(gpx_handle* h, int mode);
 int gpx_profile_reset(gpx_handle* h);

@@ -12,8 +12,8 @@ c.profile_reset(); c.profile_mode(1)
 c.fit_predict_async(p,0.0); c.fetch_results()
 c.profile_dump("gpurun_out/timeline.csv")
 rows=[l.strip().split(",") for l in open("gpurun_out/timeline.csv")][1:]
-names={0:"gram",1:"gramX",2:"POTRF",3:"trsm",4:"upd",5:"epi",6:"TOTAL"}
+names={0:"gram",1:"gramX",2:"POTRF",3:"trsm",4:"BULK",5:"epi",6:"TOTAL",7:"la"}
 ev=[(int(r[0]),float(r[1]),float(r[2])) for r in rows]
-for s,a,b in ev[:40]: print(f"{names[s]:6s} {a:8.1f} -> {b:8.1f}  ({b-a:6.1f})")
+for s,a,b in ev[:52]: print(f"{names[s]:6s} {a:8.1f} -> {b:8.1f}  ({b-a:6.1f})")
 tot=[e for e in ev if e[0]==6][0]; print("total", tot[2]-tot[1])
 # critical stream idle estimate: sum of gaps between consecutive potrf/trsm and small-upd events
