@@ -70,6 +70,50 @@ def _committed_traffic(kernel):
         return None
 
 
+def bench_distributed(args, rank, local_rank, world, dist, torch):
+    """Config C4 family: one N x N factorisation distributed by block rows over the ranks (RCCL broadcast of
+    the panel factor + all-gather of the panel column per step).  Strong scaling: the job is ONE fit+predict."""
+    import gpax_amd
+    from gpax_amd.dist import DistributedStep
+
+    n, d, m = args.n, args.d, args.m
+    kind = gpax_amd.RBF if args.kind == "rbf" else gpax_amd.MATERN52
+    x, y, x_new = synthetic_problem(n, d, m, seed=0)
+    params = gpax_amd.make_params(kind, 1.0, 1.0, None, np.array([0.006744897501960818]), 1e-6, True)
+    step = DistributedStep(x, x_new, y - 1.0, device=local_rank)
+    for _ in range(args.warmup):
+        step.fit_predict(params, np.ones(m), 0.0)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info, logp, mean, var = step.fit_predict(params, np.ones(m), 0.0)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert info == 0 and np.isfinite(logp) and (var > 0).all()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "exact-GP fit+predict points/sec (NxN RBF, fp64)", "value": n * args.steps / elapsed, "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"ExactGP {args.kind.upper()} d={d}, N={n} / M={m}: ONE factorisation, row-block-cyclic over {world} GPU(s), "
+                                   "RCCL broadcast of inv(L_kk) + all-gather of the panel per step", "n": n, "d": d, "m": m,
+                       "parallelism": f"row-block-cyclic x{world}"},
+            "logp": logp,
+        }))
+    step.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,6 +124,9 @@ def main():
     ap.add_argument("--m", type=int, default=1000)
     ap.add_argument("--kind", default="rbf", choices=["rbf", "matern52"])
     ap.add_argument("--nb", type=int, default=0)
+    ap.add_argument("--workload", default="draws", choices=["draws", "dist"],
+                    help="draws: independent hyper-parameter draws per rank (default, weak scaling); "
+                         "dist: ONE factorisation row-block-cyclic over the ranks with RCCL panel broadcasts (config C4, strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
@@ -104,6 +151,9 @@ def main():
     torch.cuda.set_device(local_rank)
 
     import gpax_amd  # raises if libgpx_hip.so is missing: no fallback
+
+    if args.workload == "dist":
+        return bench_distributed(args, rank, local_rank, world, dist, torch)
 
     core = gpax_amd.Core(local_rank)
     if args.nb:

@@ -79,6 +79,23 @@ SIGNATURES = {
     "gpx_profile_reset": (C.c_int, [C.c_void_p]),
     "gpx_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
     "gpx_profile_get": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64), _dp, _dp]),
+    # include/gpx_dist.h
+    "gpx_dist_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _dp, C.c_int64, C.c_int32, _dp, C.c_int64]),
+    "gpx_dist_set_targets": (C.c_int, [C.c_void_p, _dp]),
+    "gpx_dist_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int64)]),
+    "gpx_dist_unique_id": (C.c_int, [C.c_char_p]),
+    "gpx_dist_comm_init": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int]),
+    "gpx_dist_comm_destroy": (C.c_int, [C.c_void_p]),
+    "gpx_dist_fit_predict": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), _dp, C.c_double, _dp, _dp, _dp]),
+    "gpx_dist_build": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), C.c_double]),
+    "gpx_dist_step_diag": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gpx_dist_step_panel": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gpx_dist_step_update": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gpx_dist_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
+                                   C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "gpx_dist_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "gpx_dist_extract_z": (C.c_int, [C.c_void_p]),
+    "gpx_dist_local_results": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.POINTER(C.c_int64), _dp, _dp, C.POINTER(C.c_int)]),
     "gpx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "gpx_get_option": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]),
 }

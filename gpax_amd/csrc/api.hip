@@ -34,15 +34,6 @@ static int ensure(gpx_handle* h, T** p, int64_t* cap, int64_t count) {
   return GPX_OK;
 }
 
-static int ensure_pinned(gpx_handle* h, int64_t count) {
-  if (count <= h->pinned_cap && h->h_pinned) return GPX_OK;
-  if (h->h_pinned) (void)hipHostFree(h->h_pinned);
-  h->h_pinned = nullptr; h->pinned_cap = 0;
-  GPX_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), (size_t)count * sizeof(double), 0));
-  h->pinned_cap = count;
-  return GPX_OK;
-}
-
 // ------------------------------------------------------------------------ profiling
 
 static hipEvent_t prof_event(gpx_handle* h) {
@@ -154,6 +145,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   if (!h) return GPX_OK;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
+  gpx_dist_free(h);
   void* bufs[] = {h->d_x, h->d_xnew, h->d_r, h->d_mnew, h->d_hyp, h->d_noise, h->d_A, h->d_L, h->d_W,
                   h->d_S, h->d_cov, h->d_z, h->d_scal, h->d_info, h->d_mean, h->d_g1, h->d_g2,
                   h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2};
@@ -258,6 +250,11 @@ static int upload_params(gpx_handle* h, hipStream_t s, const gpx_kernel_params* 
     *noise_dev = h->d_noise;
   }
   return GPX_OK;
+}
+
+int gpx_upload_params(gpx_handle* h, hipStream_t s, const gpx_kernel_params* p, int64_t n, int d,
+                      const double** noise_dev, double* noise_scalar, double new_noise) {
+  return upload_params(h, s, p, n, d, noise_dev, noise_scalar, new_noise);
 }
 
 // k(x, x) without the diagonal rule: the kernel formulae at r2 = 0 (Matern keeps the 1e-12).

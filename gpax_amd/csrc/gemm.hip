@@ -24,7 +24,17 @@ struct GemmArgs {
   double alpha, beta;
   int64_t row_off, col_off;
   int lower, b_lower_tri;
+  // block-cyclic row distribution (distributed factorisation): local row m is global row
+  // ((m / cyc_nb) * cyc_P + cyc_r) * cyc_nb + m % cyc_nb;  cyc_P <= 1: rows are global already
+  int cyc_P, cyc_r, cyc_nb;
 };
+
+// first global row of the tile whose first (local) row is row_off + m0
+__device__ __forceinline__ int64_t tile_global_row(const GemmArgs& g, int64_t m0) {
+  int64_t r = g.row_off + m0;
+  if (g.cyc_P > 1) r = ((r / g.cyc_nb) * g.cyc_P + g.cyc_r) * g.cyc_nb + r % g.cyc_nb;
+  return r;
+}
 
 #define GEMM_BK 32
 #define GEMM_LDT (GEMM_BK + 2)
@@ -40,7 +50,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-  if (g.lower && (g.row_off + m0 + BM - 1 < g.col_off + n0)) return;  // tile strictly above the diagonal
+  if (g.lower && (tile_global_row(g, m0) + BM - 1 < g.col_off + n0)) return;  // tile strictly above the diagonal
 
   int64_t kend = g.K;
   if (g.b_lower_tri) {  // B[n][k] == 0 for k > n: K beyond the tile's last row is dead
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
-  if (g.lower && (g.row_off + m0 + 31 < g.col_off + n0)) return;
+  if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
   const double* Ag = g.A + m0 * g.lda;
   const double* Bg = g.B + n0 * g.ldb;
   v2d ra[2][NCH], rb[2][NCH];
@@ -338,9 +348,10 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.A = L.A; g.B = L.B; g.C = L.C; g.lda = L.lda; g.ldb = L.ldb; g.ldc = L.ldc;
   g.M = L.M; g.N = L.N; g.K = L.K; g.alpha = L.alpha; g.beta = L.beta;
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
+  g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   dim3 grid((unsigned)(L.N / bm), (unsigned)(L.M / bm));
   // the persistent pipelined kernel serves the lower-trapezoid updates with C accumulation
-  if (!L.small_tile && L.variant == 1 && L.lower && L.beta != 0.0 && L.row_off == L.col_off && L.M >= L.N && L.K >= 2 * GEMM_BK) {
+  if (!L.small_tile && L.variant == 1 && L.cyc_P <= 1 && L.lower && L.beta != 0.0 && L.row_off == L.col_off && L.M >= L.N && L.K >= 2 * GEMM_BK) {
     const int64_t ntj = L.N / 64, nti = L.M / 64;
     const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
     const int64_t slots = 256 * 3;   // CUs x resident workgroups (140 VGPRs -> 3 waves/SIMD)

@@ -6,6 +6,7 @@
 
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gpx.h"
@@ -50,6 +51,7 @@ struct GramLaunch {
   int lower_only;       // skip tiles strictly above the diagonal (x1 == x2 layouts)
   int diag_rule;        // add noise+jitter on the diagonal
   const double* noise;  // device vector (n1) or NULL
+  const int64_t* row_gid = nullptr;  // device: global row id per x1 row (diagonal rule / noise index); NULL: row itself
   double noise_scalar;  // used when noise == NULL
   double jitter;
 };
@@ -67,6 +69,7 @@ struct GemmLaunch {
   int b_lower_tri;      // B is lower triangular (B[n][k] = 0 for k > n): skip dead K
   int small_tile;       // 1: 32x32 workgroup tiles (latency path), 0: 64x64 (throughput path)
   int variant = 0;      // 64x64 path: 0 = one workgroup per tile, 1 = persistent tile-pipelined kernel
+  int cyc_P = 1, cyc_r = 0, cyc_nb = 128;   // block-cyclic local->global row map for the `lower` test (distributed path)
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
 
@@ -100,6 +103,26 @@ struct EpilogueLaunch {
   double* mean; double* var;     // device (m)
 };
 int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
+
+// post_reduce only (mean / variance of m rows of V^T against z)
+int launch_post_reduce(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
+
+// ---------------------------------------------------------------- distributed state (dist.hip)
+struct DistState {
+  bool configured = false, have_r = false;
+  int rank = 0, P = 1, d = 0;
+  int64_t n = 0, m = 0, npad = 0, nblk = 0, eblk = 0, RB = 0, nloc = 0, ld = 0, chunk_rows = 0;
+  int kind = 0; double k_scale = 0, k_jitter = 0;
+  double *A = nullptr, *L = nullptr, *W = nullptr, *send = nullptr, *recv = nullptr, *panel = nullptr;
+  double *xloc = nullptr, *r = nullptr, *z = nullptr, *small = nullptr, *red = nullptr;
+  int64_t* gid = nullptr; int* type = nullptr;
+  int64_t a_cap = 0, l_cap = 0, w_cap = 0, send_cap = 0, recv_cap = 0, panel_cap = 0, xloc_cap = 0, r_cap = 0, z_cap = 0,
+          small_cap = 0, red_cap = 0, gid_cap = 0, type_cap = 0;
+  int r_owner = 0; int64_t r_local_row = -1;
+  std::vector<std::pair<int64_t, int64_t>> test_rows;   // (local row, test index) of the k_cross rows held here
+  void* comm = nullptr;                                  // ncclComm_t
+};
+void gpx_dist_free(gpx_handle* h);
 
 // ------------------------------------------------------------------------ the handle
 struct StageProf {
@@ -166,6 +189,8 @@ struct gpx_handle {
   std::vector<hipEvent_t> ev_panel, ev_trail;
   hipEvent_t ev_join = nullptr, ev_join2 = nullptr;
   std::vector<hipEvent_t> ev_far;
+
+  DistState dist;
 
   // profiling
   int prof_mode = 0;

@@ -28,6 +28,7 @@ struct GramArgs {
   const double* hyp;     // length[d], period[d]
   const double* dev_scalars;  // device {k_scale, noise_scalar, jitter} or nullptr (then the by-value fields)
   const double* noise;   // per-row noise or nullptr
+  const int64_t* row_gid;   // global id of each x1 row (distributed path) or nullptr
   double* out;
   int64_t n1, n2, ld;
   int d;
@@ -122,8 +123,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
       } else {
         k = k_scale * exp(-2.0 * r2);                       // kernels.py:165
       }
-      if (g.diag_rule && row == col + c) {
-        const double nz = g.noise ? g.noise[row] : noise_scalar;
+      const int64_t grow = g.row_gid ? g.row_gid[row] : row;
+      if (g.diag_rule && grow == col + c) {
+        const double nz = g.noise ? g.noise[grow] : noise_scalar;
         k += (nz + jitter);                                 // kernels.py:124-125
       }
       kv[c] = k;
@@ -143,6 +145,7 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   if (L.n1 <= 0 || L.n2 <= 0) return GPX_OK;
   GramArgs g;
   g.x1 = L.x1; g.x2 = L.x2; g.hyp = L.hyp; g.dev_scalars = L.dev_scalars; g.noise = L.noise; g.out = L.out;
+  g.row_gid = L.row_gid;
   g.n1 = L.n1; g.n2 = L.n2; g.ld = L.ld; g.d = L.d;
   g.lower_only = L.lower_only; g.diag_rule = L.diag_rule;
   g.k_scale = L.k_scale; g.noise_scalar = L.noise_scalar; g.jitter = L.jitter;

@@ -373,7 +373,6 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
                                                                  int64_t ldl, double* __restrict__ W,
                                                                  int* info, int col0) {
   constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
-  constexpr int TPW = (NTRI + NWAVES - 1) / NWAVES;   // lower tiles per wave (load phase)
   __shared__ double sm[2 * NTRI * 256 + LEAF_SHARE_DOUBLES];
   double* Lt = sm;
   double* Wt = sm + NTRI * 256;

@@ -72,6 +72,14 @@ int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
   return GPX_OK;
 }
 
+int launch_post_reduce(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
+  if (e.m <= 0) return GPX_OK;
+  hipLaunchKernelGGL(post_reduce_kernel, dim3((unsigned)e.m), dim3(256), 0, s, e.vt, e.vt_ld, e.n, e.z, e.m_new, e.prior_diag,
+                     e.dev_prior_diag, e.mean, e.var);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
 // y[0:ncols) = beta*y + alpha * sum_{r<nrows} x[r] * A[r][0:ncols)    (A row-major: coalesced along c)
 __global__ __launch_bounds__(256) void gemv_t_kernel(const double* A, int64_t lda, int nrows,
                                                     int64_t ncols, const double* x, double* y,

@@ -10,9 +10,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "gpx.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(gpx_[a-z_]+)\s*\(", text)))
+    import glob
+
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        text = open(path).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(gpx_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_symbols_exported():
@@ -22,7 +27,7 @@ def test_header_symbols_exported():
     names = _declared_symbols()
     assert len(names) >= 20
     for name in names:
-        assert hasattr(lib, name), f"{name} declared in include/gpx.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert lib.gpx_abi_version() == 1
 
