@@ -32,7 +32,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # AMD MI355X datasheet fp64 matrix (= vector) peak (the local guides list no fp64 MFMA figure)
-FP64_MFMA_MEASURED_TFLOPS = 49.3  # tools/peaks on this chip: v_mfma_f64_16x16x4_f64 issues every ~100 cycles/SIMD at 2.39 GHz (profiles/r01_peaks.txt)
+# tools/peaks on this chip (profiles/r01_peaks.txt): v_mfma_f64_16x16x4_f64 issues every 65 cycles/SIMD at 2.39 GHz with
+# VGPR accumulators = 77.5 TFLOP/s (with AGPR accumulators, hipcc's default at a 512-register budget, only every ~100: 49 TFLOP/s)
+FP64_MFMA_MEASURED_TFLOPS = 77.5
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
 

@@ -12,8 +12,12 @@
 // kernel is MFMA-bound with very little operand traffic: a 2x2 register block per wave
 // needs only 4 ds_read_b64 per 4 MFMAs (256 cycles).  Tiles are staged global -> registers
 // -> LDS (one register set, written after the barrier; the next tile's global loads are in
-// flight during the MFMAs).  LDS rows are padded to 34 doubles: row stride = 68 dwords = 4 (mod
-// 64) makes the 16-row x 2-k fragment read of each 32-lane half hit 64 distinct banks.
+// flight during the MFMAs).  Fragments are read 16 B at a time (ds_read_b128, 256 B/clk; a
+// ds_read2_b64 runs at half that and made this kernel LDS-bound once the MFMAs issued every 64
+// cycles): lane (i, g) takes k = 8s+2g, 8s+2g+1 of row i and feeds them to two consecutive MFMA
+// steps -- a permutation of the k index applied to A and B alike, so the sum over k is unchanged.
+// LDS rows are padded to 36 doubles: row stride = 72 dwords = 8 (mod 64) makes the ds_read_b128
+// lane groups ({0-3,12-15,20-27}, ...) hit 16 distinct 4-bank slots.
 
 #include "gpx_internal.h"
 
@@ -37,10 +41,24 @@ __device__ __forceinline__ int64_t tile_global_row(const GemmArgs& g, int64_t m0
 }
 
 #define GEMM_BK 32
-#define GEMM_LDT (GEMM_BK + 2)
+#define GEMM_LDT (GEMM_BK + 4)
+
+// Diagnostic build only (tools/gemm_bench): s_memtime stamps of one workgroup's phases.
+#ifdef GPX_GEMM_STAMPS
+__device__ unsigned long long* g_gemm_stamps;
+#define GEMM_STAMP(slot)                                                                         \
+  do {                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == gridDim.y - 2) g_gemm_stamps[slot] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define GEMM_STAMP(slot) do { } while (0)
+#endif
 
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
+// (256, 2): a register budget of 256 makes hipcc keep the accumulators in VGPRs.  With the default budget it
+// puts them in AGPRs, and v_mfma_f64_16x16x4_f64 with an AGPR accumulator issues every ~100 cycles instead of
+// 64 (tools/peaks: 49 vs 78 TFLOP/s) -- the single largest factor in this kernel's throughput.
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int TM = BM / 32, TN = BN / 32;        // 16x16 MFMA tiles per wave (waves as 2 x 2)
   constexpr int NA = BM * (GEMM_BK / 2) / 256;      // 16-B chunks per thread, A tile
   constexpr int NBc = BN * (GEMM_BK / 2) / 256;
@@ -106,29 +124,39 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
     }
   };
 
-  const double* Ap = &As[(wm * (BM / 2) + fr) * GEMM_LDT + fk];
-  const double* Bp = &Bs[(wn * (BN / 2) + fr) * GEMM_LDT + fk];
+  const double* Ap = &As[(wm * (BM / 2) + fr) * GEMM_LDT + 2 * fk];
+  const double* Bp = &Bs[(wn * (BN / 2) + fr) * GEMM_LDT + 2 * fk];
 
+  GEMM_STAMP(0);
   load_tiles(0);
   for (int64_t k0 = 0; k0 < kend; k0 += GEMM_BK) {
     store_tiles();
+    GEMM_STAMP(1 + 3 * (int)(k0 / GEMM_BK));
     __syncthreads();
+    GEMM_STAMP(2 + 3 * (int)(k0 / GEMM_BK));
     if (k0 + GEMM_BK < kend) load_tiles(k0 + GEMM_BK);  // in flight during the MFMAs below
 #pragma unroll
-    for (int s = 0; s < GEMM_BK / 4; ++s) {
-      double a[TM], b[TN];
+    for (int s = 0; s < GEMM_BK / 8; ++s) {
+      v2d a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = Ap[i * 16 * GEMM_LDT + 4 * s];
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const v2d*>(Ap + i * 16 * GEMM_LDT + 8 * s);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bp[j * 16 * GEMM_LDT + 4 * s];
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const v2d*>(Bp + j * 16 * GEMM_LDT + 8 * s);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
     }
+    GEMM_STAMP(3 + 3 * (int)(k0 / GEMM_BK));
     __syncthreads();
   }
+  GEMM_STAMP(13);
 
   // epilogue: lane (col = l&15, row group = l>>4), reg r -> row = (l>>4) + 4r
 #pragma unroll
@@ -152,7 +180,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs g) {
 // chunk -- of the same tile or of the next one -- and the next tile's C tile is fetched two
 // stages ahead into spare registers; the store of tile t overlaps the first chunk of tile t+1.
 // Tiles are enumerated over the lower trapezoid only (no empty workgroups).
-__global__ __launch_bounds__(256) void gemm_nt_persist_kernel(GemmArgs g, int ntj, int64_t ntiles) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(GemmArgs g, int ntj, int64_t ntiles) {
   constexpr int BM = 64, BN = 64, TM = 2, TN = 2;
   constexpr int NA = BM * (GEMM_BK / 2) / 256, NBc = BN * (GEMM_BK / 2) / 256;
   __shared__ __attribute__((aligned(16))) double As[BM * GEMM_LDT];
@@ -212,8 +240,8 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(GemmArgs g, int nt
   decode(t, m0, n0);
   load_chunk(m0, n0, 0);
   load_c(m0, n0);
-  const double* Ap = &As[(wm * 32 + fr) * GEMM_LDT + fk];
-  const double* Bp = &Bs[(wn * 32 + fr) * GEMM_LDT + fk];
+  const double* Ap = &As[(wm * 32 + fr) * GEMM_LDT + 2 * fk];
+  const double* Bp = &Bs[(wn * 32 + fr) * GEMM_LDT + 2 * fk];
   v4d acc[TM][TN];
   for (; t < ntiles; t += gridDim.x) {
     const int64_t tn = t + gridDim.x;
@@ -241,17 +269,22 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(GemmArgs g, int nt
       }
       if (c == 1 && has_next) load_c(m1, n1);   // cnext is free again from chunk 0 on
 #pragma unroll
-      for (int s = 0; s < GEMM_BK / 4; ++s) {
-        double a[TM], b[TN];
+      for (int s = 0; s < GEMM_BK / 8; ++s) {
+        v2d a[TM], b[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = Ap[i * 16 * GEMM_LDT + 4 * s];
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const v2d*>(Ap + i * 16 * GEMM_LDT + 8 * s);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Bp[j * 16 * GEMM_LDT + 4 * s];
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const v2d*>(Bp + j * 16 * GEMM_LDT + 8 * s);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
       }
       __syncthreads();
     }
@@ -277,13 +310,12 @@ __global__ __launch_bounds__(256) void gemm_nt_persist_kernel(GemmArgs g, int nt
 // (A register-only variant with per-lane contiguous K chunks was tried and measured slower:
 // its loads touch 64 different cache lines per instruction.)
 template <int K>
-__global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
-  // LDS holds HALF of K at a time (K/2 + 2 doubles per row; stride = 2 mod 32 doubles keeps the
-  // fragment reads conflict-free): 34 KB at K = 128, so four workgroups fit a CU and even the widest
+__global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
+  // LDS holds HALF of K at a time (K/2 + 4 doubles per row): 34 KB at K = 128, so four workgroups fit a CU and even the widest
   // panel of the factorisation is resident in a single round.  All global loads of BOTH halves are in
   // flight together; the second half waits in registers while the first is in the MFMAs.
   constexpr int KH = K / 2;
-  constexpr int LD = KH + 2;
+  constexpr int LD = KH + 4;   // stride 8 (mod 64) dwords: conflict-free ds_read_b128 fragment reads
   constexpr int NCH = 32 * (KH / 2) / 256;   // 16-B chunks per thread, operand and half
   __shared__ __attribute__((aligned(16))) double As[32 * LD];
   __shared__ __attribute__((aligned(16))) double Bs[32 * LD];
@@ -309,8 +341,8 @@ __global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) cin[r] = cp[(int64_t)(4 * r) * g.ldc];
   }
-  const double* Ap = &As[(wm * 16 + fr) * LD + fk];
-  const double* Bp = &Bs[(wn * 16 + fr) * LD + fk];
+  const double* Ap = &As[(wm * 16 + fr) * LD + 2 * fk];
+  const double* Bp = &Bs[(wn * 16 + fr) * LD + 2 * fk];
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
@@ -323,9 +355,11 @@ __global__ __launch_bounds__(256) void gemm_nt_onepass_kernel(GemmArgs g) {
     }
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < KH / 4; s += 2) {
-      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s], Bp[4 * s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Ap[4 * s + 4], Bp[4 * s + 4], acc1, 0, 0, 0);
+    for (int s = 0; s < KH / 8; ++s) {   // 16-B fragment reads: k = 8s + 2g, 8s + 2g + 1 (same permutation for A and B)
+      const v2d a = *reinterpret_cast<const v2d*>(Ap + 8 * s);
+      const v2d b = *reinterpret_cast<const v2d*>(Bp + 8 * s);
+      acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc1, 0, 0, 0);
     }
   }
 #pragma unroll
@@ -357,6 +391,12 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     const int64_t slots = 256 * 3;   // CUs x resident workgroups (140 VGPRs -> 3 waves/SIMD)
     dim3 pg((unsigned)(ntiles < slots ? ntiles : slots));
     hipLaunchKernelGGL(gemm_nt_persist_kernel, pg, dim3(256), 0, s, g, (int)ntj, ntiles);
+    GPX_HIP_CHECK(h, hipGetLastError());
+    return GPX_OK;
+  }
+  if (!L.small_tile && L.variant == 2 && L.M % 128 == 0 && L.N % 128 == 0) {
+    dim3 g128((unsigned)(L.N / 128), (unsigned)(L.M / 128));
+    hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), g128, dim3(256), 0, s, g);
     GPX_HIP_CHECK(h, hipGetLastError());
     return GPX_OK;
   }

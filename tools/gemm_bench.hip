@@ -1,4 +1,5 @@
 // Standalone timing of the GEMM kernels at the shapes of the factorisation (diagnostic, not shipped).
+#define GPX_GEMM_STAMPS 1
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -12,19 +13,27 @@ int main(int argc, char** argv) {
   srand(3); for (auto& v : h) v = rand() / (double)RAND_MAX - 0.5;
   CK(hipMemcpy(A, h.data(), rows * ld * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(L, h.data(), rows * ld * 8, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  unsigned long long* dst; CK(hipMalloc(&dst, 64 * 8)); CK(hipMemset(dst, 0, 64 * 8));
+  CK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_stamps), &dst, sizeof(dst)));
   for (int k : {0, 4, 8, 16, 24}) {
     const int64_t c0 = k * nb, r0 = c0 + nb, r1 = r0 + nb, mr = rows - r1, ncols = npad - r1;
     GemmLaunch t;
     t.A = L + r1 * ld + c0; t.lda = ld; t.B = L + r1 * ld + c0; t.ldb = ld; t.C = A + r1 * ld + r1; t.ldc = ld;
     t.M = mr; t.N = ncols; t.K = nb; t.alpha = -1.0; t.beta = 1.0; t.lower = 1; t.row_off = r1; t.col_off = r1; t.b_lower_tri = 0;
     const double entries = (double)ncols * (ncols + 1) / 2.0 + (double)(mr - ncols) * ncols;
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < 3; variant += 2) {
       t.small_tile = 0; t.variant = variant;
       for (int w = 0; w < 3; ++w) launch_gemm_nt(nullptr, 0, t);
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0)); for (int r = 0; r < 10; ++r) launch_gemm_nt(nullptr, 0, t); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
       float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
       printf("trailing k=%2d M=%lld N=%lld variant %d: %.1f us  %.1f TFLOP/s\n", k, (long long)mr, (long long)ncols, variant, ms * 1e3, 2.0 * entries * nb / ms * 1e-9);
+      if (variant == 0) {
+        unsigned long long st[16]; CK(hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost));
+        printf("   one workgroup: first load+store %llu | ", st[1] - st[0]);
+        for (int c = 0; c < 4; ++c) printf("chunk %d: barrier %llu, mfma %llu, (next store) %llu | ", c, st[2 + 3 * c] - st[1 + 3 * c], st[3 + 3 * c] - st[2 + 3 * c], (c < 3 ? st[4 + 3 * c] : st[13]) - st[3 + 3 * c]);
+        printf(" total to epilogue %llu cycles\n", st[13] - st[0]);
+      }
     }
     // panel-solve shape
     GemmLaunch g; g.A = A + r0 * ld + c0; g.lda = ld; g.B = L; g.ldb = nb; g.C = L + r0 * ld + c0; g.ldc = ld;

@@ -10,8 +10,26 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
 
+// (256, 2): accumulators in VGPRs; with the default register budget hipcc uses AGPR accumulators and the
+// f64 MFMA then issues every ~100 cycles instead of 64 (mfma_loop_agpr below keeps that form for the record)
 template <int NACC>
-__global__ __launch_bounds__(256) void mfma_loop(double* out, int iters, double a0, double b0) {
+__global__ __launch_bounds__(256, 2) void mfma_loop(double* out, int iters, double a0, double b0) {
+  v4d acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+  double a = a0 + threadIdx.x * 1e-3, b = b0 - threadIdx.x * 1e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == 12345.678) out[0] = s;
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_loop_agpr(double* out, int iters, double a0, double b0) {
   v4d acc[NACC];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -38,6 +56,33 @@ __global__ __launch_bounds__(256) void fma_loop(double* out, int iters, double a
   double s = 0.0;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += x[i];
+  if (s == 12345.678) out[0] = s;
+}
+
+// co-issue probe: half the waves of a 512-thread block run the MFMA loop, the other half the VALU FMA loop
+template <int MFMA_WAVES>
+__global__ __launch_bounds__(512) void coissue_loop(double* out, int iters, double a0) {
+  const int wave = threadIdx.x >> 6;
+  double s = 0.0;
+  if (wave < MFMA_WAVES) {
+    v4d acc[4];
+    for (int i = 0; i < 4; ++i) acc[i] = (v4d){0.0, 0.0, 0.0, 0.0};
+    double a = a0 + threadIdx.x * 1e-3, b = 2.0 - threadIdx.x * 1e-3;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    for (int i = 0; i < 4; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  } else {
+    double x[8];
+    for (int i = 0; i < 8; ++i) x[i] = a0 + i + threadIdx.x * 1e-3;
+    const double m = 1.0000001, c = 1e-9;
+    for (int it = 0; it < iters * 14; ++it) {   // ~ the same wall time as the MFMA half
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = fma(x[i], m, c);
+    }
+    for (int i = 0; i < 8; ++i) s += x[i];
+  }
   if (s == 12345.678) out[0] = s;
 }
 
@@ -93,6 +138,8 @@ int main() {
     dim3 grid(cus * wpc / 4), block(256);
     float ms8 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<8>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
     printf("mfma_f64_16x16x4 waves/CU=%d: 8 acc %.2f TFLOP/s\n", wpc, 2048.0 * iters * 8 * (double)grid.x * 4 / ms8 * 1e-9);
+    float msa = time_ms([&] { hipLaunchKernelGGL(mfma_loop_agpr<4>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
+    printf("mfma_f64_16x16x4 waves/CU=%d: 4 acc in AGPRs (default register budget) %.2f TFLOP/s\n", wpc, 2048.0 * iters * 4 * (double)grid.x * 4 / msa * 1e-9);
     float ms1 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<1>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
     float ms4 = time_ms([&] { hipLaunchKernelGGL(mfma_loop<4>, grid, block, 0, 0, out, iters, 1.0, 2.0); }, 5);
     double fl1 = 2048.0 * iters * 1 * (double)grid.x * 4, fl4 = 2048.0 * iters * 4 * (double)grid.x * 4;
@@ -107,6 +154,19 @@ int main() {
     unsigned long long hc[2]; CHECK(hipMemcpy(hc, clk, 16, hipMemcpyDeviceToHost));
     printf("in-kernel clock under fp64 MFMA load: %.0f MHz; cycles per MFMA per SIMD (2 waves/SIMD, 4 acc): %.1f\n",
            (double)hc[0] / (double)hc[1] * 100.0, (double)hc[0] / ((double)(1 << 16) * 4 * 2));
+  }
+  {
+    // 4 MFMA waves + 4 VALU waves per block, 2 blocks per CU
+    dim3 grid(cus * 2), block(512);
+    const int it2 = 2048;
+    float ms = time_ms([&] { hipLaunchKernelGGL(coissue_loop<4>, grid, block, 0, 0, out, it2, 1.0); }, 5);
+    const double fl_mfma = 2048.0 * it2 * 4 * (double)grid.x * 4, fl_valu = 2.0 * 8 * 64 * (double)it2 * 14 * (double)grid.x * 4;
+    printf("co-issue (4 MFMA waves + 4 VALU waves per block): %.2f TFLOP/s total (MFMA part %.2f + VALU part %.2f if both spanned the whole kernel), %.3f ms\n",
+           (fl_mfma + fl_valu) / ms * 1e-9, fl_mfma / ms * 1e-9, fl_valu / ms * 1e-9, ms);
+    float ms_m = time_ms([&] { hipLaunchKernelGGL(coissue_loop<8>, grid, block, 0, 0, out, it2, 1.0); }, 5);
+    float ms_v = time_ms([&] { hipLaunchKernelGGL(coissue_loop<0>, grid, block, 0, 0, out, it2, 1.0); }, 5);
+    printf("  same kernel, all 8 waves MFMA: %.3f ms (%.2f TFLOP/s); all 8 waves VALU: %.3f ms (%.2f TFLOP/s)\n", ms_m,
+           2.0 * fl_mfma / ms_m * 1e-9, ms_v, 2.0 * fl_valu / ms_v * 1e-9);
   }
   {
     dim3 grid(cus * 8), block(256);   // 8 waves per SIMD worth of blocks
