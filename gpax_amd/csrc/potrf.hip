@@ -125,6 +125,31 @@ __device__ __forceinline__ void tile_syrk(double* Cp, const double* Ap, const do
   for (int r = 0; r < 4; ++r) Cp[eix(fk + 4 * r, fr)] = acc0[r] + acc1[r];
 }
 
+// Two independent C -= A * B^T tile updates in one instruction stream: the LDS-read -> MFMA -> LDS-write
+// chain of a single tile is latency bound (~1.5k cycles), two interleaved chains hide each other.
+__device__ __forceinline__ void tile_syrk2(double* C0, const double* A0, const double* B0, double* C1, const double* A1,
+                                           const double* B1, int fr, int fk) {
+  v4d p0, p1, q0 = {0.0, 0.0, 0.0, 0.0}, q1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { p0[r] = C0[eix(fk + 4 * r, fr)]; p1[r] = C1[eix(fk + 4 * r, fr)]; }
+  double a0[4], b0[4], a1[4], b1[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    a0[s] = -A0[eix(fr, 4 * s + fk)]; b0[s] = B0[eix(fr, 4 * s + fk)];
+    a1[s] = -A1[eix(fr, 4 * s + fk)]; b1[s] = B1[eix(fr, 4 * s + fk)];
+  }
+  p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], p0, 0, 0, 0);
+  p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], p1, 0, 0, 0);
+  q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], q0, 0, 0, 0);
+  q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], q1, 0, 0, 0);
+  p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[2], b0[2], p0, 0, 0, 0);
+  p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[2], b1[2], p1, 0, 0, 0);
+  q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[3], b0[3], q0, 0, 0, 0);
+  q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[3], b1[3], q1, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { C0[eix(fk + 4 * r, fr)] = p0[r] + q0[r]; C1[eix(fk + 4 * r, fr)] = p1[r] + q1[r]; }
+}
+
 // W tile (jb, cb), cb < jb:  T = sum_{kb=cb}^{jb-1} L_jb,kb * W_kb,cb ;  W_jb,cb = -inv(L_jj) * T
 __device__ __forceinline__ void tile_winv(double* Lt, double* Wt, int jb, int cb, int fr, int fk) {
   double* Tp = Wt + tix(jb, cb) * 256;
@@ -460,16 +485,25 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
       } else {
         const int tn = NT - 1 - jb;
         const int ntiles = tn * (tn + 1) / 2;
-        for (int q = wave - 1; q < ntiles + jb; q += NWAVES - 2) {   // q = 0 is wave 0's tile
-          if (q < ntiles) {
-            int ib2 = 0, q2 = q;
-            while (q2 > ib2) { q2 -= ib2 + 1; ++ib2; }
-            const int ib = jb + 1 + ib2, lb = jb + 1 + q2;
-            tile_syrk(Lt + tix(ib, lb) * 256, Lt + tix(ib, jb) * 256, Lt + tix(lb, jb) * 256, fr, fk);
+        // rank-16 update tiles q = 1 .. ntiles-1 (q = 0 is wave 0's), two per wave and iteration
+        auto tile_of = [&](int q, double*& Cp, const double*& Ap, const double*& Bp) {
+          int ib2 = 0, q2 = q;
+          while (q2 > ib2) { q2 -= ib2 + 1; ++ib2; }
+          const int ib = jb + 1 + ib2, lb = jb + 1 + q2;
+          Cp = Lt + tix(ib, lb) * 256; Ap = Lt + tix(ib, jb) * 256; Bp = Lt + tix(lb, jb) * 256;
+        };
+        constexpr int SW = NWAVES - 2;   // waves sharing the shadow work
+        for (int q = 1 + 2 * (wave - 2); q < ntiles; q += 2 * SW) {
+          double *C0, *C1; const double *A0, *B0, *A1, *B1;
+          tile_of(q, C0, A0, B0);
+          if (q + 1 < ntiles) {
+            tile_of(q + 1, C1, A1, B1);
+            tile_syrk2(C0, A0, B0, C1, A1, B1, fr, fk);
           } else {
-            tile_winv(Lt, Wt, jb, q - ntiles, fr, fk);   // row jb of W: off the critical path
+            tile_syrk(C0, A0, B0, fr, fk);
           }
         }
+        for (int cb = wave - 2; cb < jb; cb += SW) tile_winv(Lt, Wt, jb, cb, fr, fk);   // row jb of W: off the critical path
         // write out what is final: column jb of L (after phase A) and row jb-1 of W (previous slot)
         for (int q = wave - 2; q < NT; q += NWAVES - 2) {
           if (q < NT - jb) store_tile(Lt, L, ldl, jb + q, jb, lane, true);
