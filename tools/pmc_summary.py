@@ -4,7 +4,7 @@ import csv, glob, json, sys, collections
 
 def per_kernel(path_glob, counter):
     out = collections.defaultdict(list)
-    for f in glob.glob(path_glob):
+    for f in glob.glob(path_glob, recursive=True):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
                 out[r["Kernel_Name"]].append((int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0), float(r["Counter_Value"])))
