@@ -7,7 +7,7 @@ the C ABI of ``include/gpx.h`` (``gpax_amd/_lib.py``).  There is no CPU fallback
 
 from gpax_amd import state  # noqa: F401
 from gpax_amd._lib import MATERN52, PERIODIC, RBF, Core, GpxError, make_params  # noqa: F401
-from gpax_amd.gp import ExactGP, GPSample  # noqa: F401
+from gpax_amd.gp import ExactGP, GPSample, VariationalInferenceGP  # noqa: F401
 from gpax_amd.kernels import MaternKernel, PeriodicKernel, RBFKernel  # noqa: F401
 
 __version__ = "0.1.0"

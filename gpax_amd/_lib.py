@@ -68,6 +68,7 @@ SIGNATURES = {
     "gpx_set_test": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
     "gpx_fit_factor": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), _dp, _dp]),
     "gpx_log_marginal": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "gpx_lml_grad": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), _dp, _dp, _dp, _dp]),
     "gpx_posterior": (C.c_int, [C.c_void_p, _dp, C.c_double, _dp, _dp, _dp]),
     "gpx_prior_cov": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), C.c_double, _dp]),
     "gpx_mvn_sample": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, _dp, C.c_int64, _dp]),
@@ -256,6 +257,27 @@ class Core:
         alpha = np.empty(self.n) if want_alpha else None
         info = self._check(self._lib.gpx_log_marginal(self._h, _ptr(r), C.byref(logp), _ptr(alpha)), "gpx_log_marginal")
         return info, logp.value, alpha
+
+    def lml_grad(self, params, y_minus_m, want_alpha=True):
+        """Log-marginal likelihood and its gradient with respect to the kernel hyper-parameters
+        (gpx_lml_grad).  Returns ``(info, logp, grads, alpha)``; ``grads`` is keyed like the kernel
+        keywords (``k_scale`` (1,), ``k_length`` (n_length,), ``k_period`` (n_period,), ``k_noise`` (1,))."""
+        p, _keep = params
+        r = _arr(y_minus_m).reshape(-1)
+        if r.size != self.n:
+            raise ValueError("y_minus_m must have n entries")
+        n_per = p.n_period if p.kind == PERIODIC else 0
+        g = np.empty(2 + p.n_length + n_per)
+        logp = C.c_double()
+        alpha = np.empty(self.n) if want_alpha else None
+        info = self._check(
+            self._lib.gpx_lml_grad(self._h, C.byref(p), _ptr(r), C.byref(logp), _ptr(g), _ptr(alpha)), "gpx_lml_grad"
+        )
+        grads = {"k_scale": g[0:1], "k_length": g[1 : 1 + p.n_length]}
+        if n_per:
+            grads["k_period"] = g[1 + p.n_length : 1 + p.n_length + n_per]
+        grads["k_noise"] = g[-1:]
+        return info, logp.value, grads, alpha
 
     def posterior(self, m_new=None, new_noise=0.0, want_mean=True, want_var=True, want_cov=False):
         mn = _arr(m_new).reshape(-1) if m_new is not None else None

@@ -28,6 +28,7 @@ struct GemmArgs {
   double alpha, beta;
   int64_t row_off, col_off;
   int lower, b_lower_tri;
+  int a_upper_tri;   // A[m][k] == 0 for k < m (rows of an upper-triangular factor): K below the tile's first row is dead
   // block-cyclic row distribution (distributed factorisation): local row m is global row
   // ((m / cyc_nb) * cyc_P + cyc_r) * cyc_nb + m % cyc_nb;  cyc_P <= 1: rows are global already
   int cyc_P, cyc_r, cyc_nb;
@@ -127,9 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const double* Ap = &As[(wm * (BM / 2) + fr) * GEMM_LDT + 2 * fk];
   const double* Bp = &Bs[(wn * (BN / 2) + fr) * GEMM_LDT + 2 * fk];
 
+  const int64_t kbeg = g.a_upper_tri ? (m0 / GEMM_BK) * GEMM_BK : 0;
   GEMM_STAMP(0);
-  load_tiles(0);
-  for (int64_t k0 = 0; k0 < kend; k0 += GEMM_BK) {
+  load_tiles(kbeg);
+  for (int64_t k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
     store_tiles();
     GEMM_STAMP(1 + 3 * (int)(k0 / GEMM_BK));
     __syncthreads();
@@ -383,6 +385,11 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.M = L.M; g.N = L.N; g.K = L.K; g.alpha = L.alpha; g.beta = L.beta;
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
+  g.a_upper_tri = L.a_upper_tri;
+  if (L.a_upper_tri && (L.small_tile || L.variant != 0)) {
+    gpx_set_error(h, "gemm_nt: a_upper_tri is served by the 64x64 kernel only");
+    return GPX_ERR_ARG;
+  }
   dim3 grid((unsigned)(L.N / bm), (unsigned)(L.M / bm));
   // the persistent pipelined kernel serves the lower-trapezoid updates with C accumulation
   if (!L.small_tile && L.variant == 1 && L.cyc_P <= 1 && L.lower && L.beta != 0.0 && L.row_off == L.col_off && L.M >= L.N && L.K >= 2 * GEMM_BK) {

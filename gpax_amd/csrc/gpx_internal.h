@@ -70,6 +70,7 @@ struct GemmLaunch {
   int small_tile;       // 1: 32x32 workgroup tiles (latency path), 0: 64x64 (throughput path)
   int variant = 0;      // 64x64 path: 0 = one workgroup per tile, 1 = persistent tile-pipelined kernel
   int cyc_P = 1, cyc_r = 0, cyc_nb = 128;   // block-cyclic local->global row map for the `lower` test (distributed path)
+  int a_upper_tri = 0;  // A[m][k] = 0 for k < m: skip the dead K range below each tile's first row (64x64 path)
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
 
@@ -106,6 +107,15 @@ int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
 
 // post_reduce only (mean / variance of m rows of V^T against z)
 int launch_post_reduce(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
+
+// gradient of the log-marginal likelihood (grad.hip)
+int grad_partials_per_chunk(void);
+int grad_chunk_dims(void);
+int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* hyp, const double* kinv,
+                       int64_t ldk, const double* alpha, int64_t n, int d, int per_dim, int nwg, double* part,
+                       double* sums);
+int launch_utri_gemv(gpx_handle* h, hipStream_t s, const double* U, int64_t ld, const double* z, double* alpha,
+                     int64_t n, int64_t ncols);
 
 // ---------------------------------------------------------------- distributed state (dist.hip)
 struct DistState {
@@ -171,6 +181,9 @@ struct gpx_handle {
   double* d_g2 = nullptr; int64_t g2_cap = 0;
   double* d_gout = nullptr; int64_t gout_cap = 0;
   double* d_vec = nullptr; int64_t vec_cap = 0;
+  // gradient workspace: K^-1 (npad x npad, lower tiles), per-workgroup partial sums, final sums
+  double* d_kinv = nullptr; int64_t kinv_cap = 0;
+  double* d_gpart = nullptr; int64_t gpart_cap = 0;
   // secondary factor buffers (Cholesky of the posterior covariance for MVN sampling)
   double* d_A2 = nullptr; int64_t a2_cap = 0;
   double* d_L2 = nullptr; int64_t l2_cap = 0;

@@ -10,9 +10,11 @@ Deviations from the reference, on purpose:
   * ``use_cholesky`` is accepted but the HIP path ALWAYS uses the Cholesky branch
     (gpax/gp.py:295-301); the reference default is the explicit inverse (:303-310), which agrees
     with it to ~cond(K)*eps (tests/test_oracle.py::test_golden_inverse_branch_gap_recorded).
-  * ``fit()`` uses a built-in HMC sampler with dual-averaging step-size adaptation in place of
-    NumPyro's NUTS (NumPyro/JAX are not part of this stack); the random streams differ from JAX's,
-    so agreement with the reference is statistical, not bitwise.
+  * ``ExactGP.fit()`` runs the NUTS sampler of ``gpax_amd.mcmc`` (NumPyro/JAX are not part of this
+    stack) on the log-marginal likelihood and its closed-form gradient from ``gpx_lml_grad``;
+    ``VariationalInferenceGP.fit()`` maximises the single-sample reparameterised ELBO of a mean-field
+    normal guide with Adam.  The random streams differ from JAX's, so agreement with the reference
+    is statistical, not bitwise.
 """
 
 from __future__ import annotations
@@ -22,7 +24,7 @@ from copy import deepcopy
 
 import numpy as np
 
-from gpax_amd import _lib, state
+from gpax_amd import _lib, mcmc, state
 from gpax_amd.kernels import Kernel
 from gpax_amd.means import ConstantMean, Mean
 from gpax_amd.transforms import IdentityTransform, NormalizeTransform, ScaleTransform, Transform
@@ -191,6 +193,34 @@ class GaussianProcess:
         r = self.y_transformed - self.mean(x, **m_params)
         info, logp, _, _ = core.fit_predict(self._kernel_struct(k_params, k_noise, k_jitter, x.shape[0]), r, None, 0.0)
         return logp if info == 0 else float("nan")
+
+    def log_marginal_and_grad(self, params):
+        """``log_marginal`` together with its gradient with respect to every entry of ``params``
+        that is a kernel hyper-parameter (``gpx_lml_grad``: closed form, one bordered factorisation)
+        or a mean-function parameter (``alpha . dm/dtheta`` with ``alpha = K^-1 (y - m)`` from the same
+        call and the O(N) mean function differentiated by central differences on the host).  This is
+        what jax.grad of the NumPyro potential provides in the reference (gpax/gp.py:515-530)."""
+        m_params, k_params, k_noise, k_jitter = self._split(params)
+        core, x = self._make_train_resident()
+        core._gp_factor = None
+        y = self.y_transformed
+        r = y - self.mean(x, **m_params)
+        info, logp, grads, alpha = core.lml_grad(self._kernel_struct(k_params, k_noise, k_jitter, x.shape[0]), r)
+        if info != 0:
+            return float("nan"), {}
+        out = {k: np.asarray(v, dtype=np.float64) for k, v in grads.items() if k in params}
+        for name, val in m_params.items():
+            val = np.atleast_1d(np.asarray(val, dtype=np.float64))
+            g = np.zeros(val.size)
+            for i in range(val.size):
+                h = 1e-6 * max(1.0, abs(val.flat[i]))
+                up, dn = val.copy(), val.copy()
+                up.flat[i] += h
+                dn.flat[i] -= h
+                dm = (self.mean(x, **{**m_params, name: up}) - self.mean(x, **{**m_params, name: dn})) / (2 * h)
+                g[i] = float(alpha @ np.broadcast_to(dm, alpha.shape))
+            out[name] = g.reshape(val.shape)
+        return logp, out
 
     def _gp_prior(self, x=None, y=None, params=None, rng=None):
         """The GP model of gpax/gp.py:133-151.  Without NumPyro there are no sample sites: with
@@ -386,6 +416,39 @@ class _ParamSpace:
     def init_to_median(self):
         return np.concatenate([np.atleast_1d(d.to_unconstrained(np.full(pl, d.median))) for _, d, pl in self.items])
 
+    def value_and_grad(self, gp, u):
+        """Log joint density in unconstrained space (priors + log|Jacobian| + log-marginal) and its
+        gradient: the potential NumPyro differentiates for NUTS / SVI, one ``gpx_lml_grad`` call."""
+        params, g_prior, dx, o = dict(self.constants), np.zeros(self.dim), np.zeros(self.dim), 0
+        log_prior = 0.0
+        with np.errstate(all="ignore"):   # far-out trial points of the step-size search overflow to a rejected -inf
+            for name, dist, plate in self.items:
+                uu = u[o : o + plate]
+                x, dxdu, gterm = dist.grad_terms(uu)
+                _, lj = dist.from_unconstrained(uu)
+                params[name] = np.asarray(x, dtype=np.float64)
+                log_prior += float(np.sum(dist.log_prob(x)) + np.sum(lj))
+                dx[o : o + plate], g_prior[o : o + plate] = dxdu, gterm
+                o += plate
+        if not np.isfinite(log_prior) or not all(np.all(np.isfinite(v)) and np.all(np.abs(v) < 1e150) for v in params.values()):
+            return -np.inf, np.zeros(self.dim)
+        logp, grads = gp.log_marginal_and_grad(params)
+        val = logp + log_prior
+        if not np.isfinite(val):
+            return -np.inf, np.zeros(self.dim)
+        g, o = g_prior.copy(), 0
+        for name, _, plate in self.items:
+            g[o : o + plate] += dx[o : o + plate] * np.broadcast_to(grads[name].reshape(-1), (plate,))
+            o += plate
+        return val, g
+
+    def constrain(self, u):
+        out, o = {}, 0
+        for name, dist, plate in self.items:
+            out[name] = np.asarray(dist.from_unconstrained(u[o : o + plate])[0], dtype=np.float64)
+            o += plate
+        return out
+
 
 class ExactGP(GaussianProcess):
     """gpax/gp.py:504-544: fully Bayesian GP; ``fit()`` samples the hyper-parameter posterior."""
@@ -399,66 +462,26 @@ class ExactGP(GaussianProcess):
         self.mcmc_run_kwargs = mcmc_run_kwargs if mcmc_run_kwargs is not None else {}
         super().__init__(*args, **kw)
 
-    def _potential(self, space, u):
-        params, lp = space.unpack(u)
-        ll = self.log_marginal(params)
-        val = ll + lp
-        return val if np.isfinite(val) else -np.inf
-
-    def _grad(self, space, u, f0=None):
-        """Central differences in the unconstrained space (2*dim log-marginal evaluations, each a
-        complete GPU factorisation).  The analytic gradient needs K^-1: next."""
-        g = np.zeros_like(u)
-        for i in range(u.size):
-            h = 1e-5 * max(1.0, abs(u[i]))
-            up, um = u.copy(), u.copy()
-            up[i] += h
-            um[i] -= h
-            fp, fm = self._potential(space, up), self._potential(space, um)
-            g[i] = (fp - fm) / (2 * h) if np.isfinite(fp) and np.isfinite(fm) else 0.0
-        return g
-
     def fit(self):
-        """Hamiltonian Monte Carlo over the hyper-parameters (gpax/gp.py:512-534: NUTS with
-        init_to_median, ``num_warmup`` adaptation steps, ``hp_samples`` kept draws per chain)."""
+        """gpax/gp.py:512-534: NUTS over the hyper-parameters with ``init_to_median``, ``num_warmup``
+        adaptation steps and ``hp_samples`` kept draws per chain (``gpax_amd.mcmc``).  Every leapfrog
+        step is one ``gpx_lml_grad`` call (log-marginal + closed-form gradient).  ``mcmc_run_kwargs``
+        may carry ``algorithm`` ("nuts" | "hmc"), ``target_accept_prob``, ``max_tree_depth``,
+        ``num_leapfrog`` (hmc), ``adapt_mass_matrix``, ``step_size``."""
         key, rng = state.get_rng_key()
         space = _ParamSpace(self)
-        samples = {name: [] for name, _, _ in space.items}
-        n_leap = int(self.mcmc_run_kwargs.get("num_leapfrog", 8))
-        target_accept = float(self.mcmc_run_kwargs.get("target_accept_prob", 0.8))
-        for _ in range(self.num_chains):
-            u = space.init_to_median()
-            logp = self._potential(space, u)
-            grad = self._grad(space, u)
-            # dual averaging (Hoffman & Gelman 2014, alg. 5)
-            eps, mu_da, hbar, log_eps_bar, gamma, t0, kappa = 0.1, math.log(1.0), 0.0, 0.0, 0.05, 10.0, 0.75
-            for it in range(self.num_warmup + self.hp_samples):
-                p0 = rng.standard_normal(u.size)
-                un, pn, gn = u.copy(), p0 + 0.5 * eps * grad, grad
-                for s in range(n_leap):
-                    un = un + eps * pn
-                    gn = self._grad(space, un)
-                    pn = pn + (eps if s < n_leap - 1 else 0.5 * eps) * gn
-                logpn = self._potential(space, un)
-                log_alpha = (logpn - 0.5 * pn @ pn) - (logp - 0.5 * p0 @ p0)
-                alpha = min(1.0, math.exp(min(0.0, log_alpha))) if np.isfinite(log_alpha) else 0.0
-                if rng.uniform() < alpha:
-                    u, logp, grad = un, logpn, gn
-                if it < self.num_warmup:
-                    m = it + 1
-                    hbar = (1 - 1 / (m + t0)) * hbar + (target_accept - alpha) / (m + t0)
-                    log_eps = mu_da - math.sqrt(m) / gamma * hbar
-                    eta = m ** (-kappa)
-                    log_eps_bar = eta * log_eps + (1 - eta) * log_eps_bar
-                    eps = math.exp(log_eps)
-                    if m == self.num_warmup:
-                        eps = math.exp(log_eps_bar)
-                else:
-                    params, _ = space.unpack(u)
-                    for name, _, _ in space.items:
-                        samples[name].append(params[name])
-        self.mcmc = {k: np.stack(v) for k, v in samples.items()}
+        kw = dict(self.mcmc_run_kwargs)
+        draws, infos = {name: [] for name, _, _ in space.items}, []
+        for _ in range(self.num_chains):   # chain_method "sequential" (gpax/gp.py:509)
+            u0 = space.init_to_median()
+            d, info = mcmc.sample(lambda u: space.value_and_grad(self, u), u0, self.num_warmup, self.hp_samples, rng, **kw)
+            for row in d:
+                for name, v in space.constrain(row).items():
+                    draws[name].append(v)
+            infos.append(info)
+        self.mcmc = {k: np.stack(v) for k, v in draws.items()}
         self.metadata["fit_key"] = np.array(key)
+        self.metadata["mcmc_info"] = infos
         self._is_fit = True
 
     def _get_hp_samples_from_posterior(self, fast):
@@ -468,3 +491,90 @@ class ExactGP(GaussianProcess):
             hp = {k: np.median(v, axis=0, keepdims=True) for k, v in hp.items()}
         n = len(next(iter(hp.values())))
         return hp, n
+
+
+class _Adam:
+    """numpyro.optim.Adam(step_size, b1, b2, eps) on one flat vector (ascent on the ELBO)."""
+
+    def __init__(self, dim, step_size=1e-3, b1=0.9, b2=0.999, eps=1e-8):
+        self.step_size, self.b1, self.b2, self.eps = step_size, b1, b2, eps
+        self.m, self.v, self.t = np.zeros(dim), np.zeros(dim), 0
+
+    def step(self, x, grad):
+        self.t += 1
+        self.m = self.b1 * self.m + (1 - self.b1) * grad
+        self.v = self.b2 * self.v + (1 - self.b2) * grad * grad
+        mhat = self.m / (1 - self.b1**self.t)
+        vhat = self.v / (1 - self.b2**self.t)
+        return x + self.step_size * mhat / (np.sqrt(vhat) + self.eps)
+
+
+def _softplus(x):
+    return np.logaddexp(0.0, x)
+
+
+class VariationalInferenceGP(GaussianProcess):
+    """gpax/gp.py:547-605: stochastic variational inference over the hyper-parameters with a
+    mean-field normal guide in unconstrained space (NumPyro's ``AutoNormal``: ``loc`` initialised at a
+    uniform draw in (-2, 2), ``scale`` at 0.1 through a softplus), the single-particle
+    reparameterised ``Trace_ELBO`` and Adam (``b1 = 0.5``, ``step_size = 1e-3`` unless given,
+    gpax/gp.py:565-569).  Each optimiser step is one ``gpx_lml_grad`` call.  Predictions use the
+    guide median only (``hp_samples`` is forced to 1, gpax/gp.py:570-576)."""
+
+    def __init__(self, *args, num_steps=100, optimizer_kwargs=None, hp_samples=1, svi=None, kernel_params=None, **kw):
+        if not isinstance(num_steps, int) or num_steps <= 0:
+            raise ValueError("num_steps must be a positive int")
+        self.num_steps = num_steps
+        self.optimizer_kwargs = dict(optimizer_kwargs) if optimizer_kwargs is not None else {}
+        self.svi, self.kernel_params = svi, kernel_params
+        super().__init__(*args, hp_samples=hp_samples, **kw)
+
+    def _class_specific_post_init(self):
+        self.optimizer_kwargs.setdefault("b1", 0.5)
+        self.optimizer_kwargs.setdefault("step_size", 1e-3)
+        if self.hp_samples != 1:
+            import warnings
+
+            warnings.warn(
+                f"hp_samples is set to {self.hp_samples} but will be overridden to 1. In VariationalInferenceGP, "
+                "only the median value of the hyperparameters are used for predictions."
+            )
+            self.hp_samples = 1
+
+    def fit(self):
+        key, rng = state.get_rng_key()
+        space = _ParamSpace(self)
+        dim = space.dim
+        loc = rng.uniform(-2.0, 2.0, dim)                 # init_to_uniform(radius=2), AutoNormal's default
+        rho = np.full(dim, math.log(math.expm1(0.1)))      # softplus(rho) = 0.1 = AutoNormal's init_scale
+        opt = _Adam(2 * dim, **self.optimizer_kwargs)
+        losses = np.empty(self.num_steps)
+        for it in range(self.num_steps):
+            eps = rng.standard_normal(dim)
+            scale = _softplus(rho)
+            u = loc + scale * eps
+            val, g = space.value_and_grad(self, u)
+            entropy = float(np.sum(np.log(scale))) + 0.5 * dim * (1.0 + math.log(2 * math.pi))
+            losses[it] = -(val + entropy)                  # Trace_ELBO loss = -ELBO, one particle
+            if np.isfinite(val):
+                dscale_drho = 1.0 / (1.0 + np.exp(-rho))
+                grad = np.concatenate([g, (g * eps + 1.0 / scale) * dscale_drho])
+                both = opt.step(np.concatenate([loc, rho]), grad)
+                loc, rho = both[:dim], both[dim:]
+        self.svi = {"loc": loc, "scale": _softplus(rho), "space": space}
+        self.kernel_params = {"params": space.constrain(loc), "losses": losses}
+        self.metadata["fit_key"] = np.array(key)
+        self._is_fit = True
+
+    def _get_hp_samples_from_posterior(self, fast):
+        """gpax/gp.py:593-605: the guide median (the unconstrained ``loc`` pushed through the bijection)."""
+        if fast:
+            import warnings
+
+            warnings.warn(
+                "Note setting fast = True for VIGP will do nothing. VIGP only uses the median value of the "
+                "hyperparameters by default.",
+                RuntimeWarning,
+            )
+        hp = {k: np.atleast_1d(v)[None] for k, v in self.svi["space"].constrain(self.svi["loc"]).items()}
+        return hp, 1

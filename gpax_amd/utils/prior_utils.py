@@ -39,6 +39,27 @@ class Distribution:
     def to_unconstrained(self, x):
         return np.log(x)
 
+    def grad_log_prob(self, x):
+        """d log_prob / dx (central differences unless a sub-class knows better)."""
+        x = np.asarray(x, dtype=np.float64)
+        h = 1e-6 * np.maximum(1.0, np.abs(x))
+        return (self.log_prob(x + h) - self.log_prob(x - h)) / (2 * h)
+
+    def grad_terms(self, u):
+        """What a gradient-based sampler needs at the unconstrained point ``u``:
+        ``(x, dx/du, d/du [log_prob(x(u)) + log|dx/du|])`` -- the role of jax.grad through NumPyro's
+        biject_to transforms."""
+        u = np.asarray(u, dtype=np.float64)
+        x, _ = self.from_unconstrained(u)
+        dx = self._dx_du(u, x)
+        return x, dx, self.grad_log_prob(x) * dx + self._dlogjac_du(u, x)
+
+    def _dx_du(self, u, x):
+        return x  # exp
+
+    def _dlogjac_du(self, u, x):
+        return np.ones_like(u)
+
 
 @dataclass
 class HalfNormal(Distribution):
@@ -52,6 +73,9 @@ class HalfNormal(Distribution):
     def log_prob(self, x):
         x = np.asarray(x, dtype=np.float64)
         return np.where(x >= 0, 0.5 * math.log(2 / math.pi) - math.log(self.scale) - 0.5 * (x / self.scale) ** 2, -np.inf)
+
+    def grad_log_prob(self, x):
+        return -np.asarray(x, dtype=np.float64) / self.scale**2
 
     @property
     def median(self):
@@ -77,6 +101,10 @@ class LogNormal(Distribution):
         x = np.asarray(x, dtype=np.float64)
         lx = np.log(x)
         return -lx - math.log(self.scale) - 0.5 * math.log(2 * math.pi) - 0.5 * ((lx - self.loc) / self.scale) ** 2
+
+    def grad_log_prob(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        return -(1.0 + (np.log(x) - self.loc) / self.scale**2) / x
 
     @property
     def median(self):
@@ -115,6 +143,16 @@ class Uniform(Distribution):
         s = (np.asarray(x, dtype=np.float64) - self.low) / (self.high - self.low)
         return np.log(s) - np.log1p(-s)
 
+    def grad_log_prob(self, x):
+        return np.zeros_like(np.asarray(x, dtype=np.float64))
+
+    def _dx_du(self, u, x):
+        s = 1.0 / (1.0 + np.exp(-u))
+        return (self.high - self.low) * s * (1.0 - s)
+
+    def _dlogjac_du(self, u, x):
+        return 1.0 - 2.0 / (1.0 + np.exp(-u))
+
 
 @dataclass
 class Normal(Distribution):
@@ -139,6 +177,15 @@ class Normal(Distribution):
 
     def to_unconstrained(self, x):
         return np.asarray(x, dtype=np.float64)
+
+    def grad_log_prob(self, x):
+        return -(np.asarray(x, dtype=np.float64) - self.loc) / self.scale**2
+
+    def _dx_du(self, u, x):
+        return np.ones_like(u)
+
+    def _dlogjac_du(self, u, x):
+        return np.zeros_like(u)
 
 
 @dataclass

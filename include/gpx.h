@@ -99,6 +99,20 @@ int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double* K_out, dou
  * alpha_out: optional (n,) = K^-1 r  (the `B` of gpax/gp.py:300). */
 int gpx_log_marginal(gpx_handle* h, const double* y_minus_m, double* logp, double* alpha_out);
 
+/* Log-marginal likelihood of gpx_log_marginal AND its gradient with respect to the kernel
+ * hyper-parameters at one setting: what jax.grad of the NumPyro potential of _gp_prior
+ * (gpax/gp.py:133-151) hands NUTS at every leapfrog step (gpax/gp.py:515-530) and SVI at every
+ * optimiser step (gpax/gp.py:583-587), here in closed form
+ *   d logp/d theta = 1/2 tr((alpha alpha^T - K^-1) dK/dtheta),  alpha = K^-1 r,
+ * with dK/dtheta of the kernels of gpax/kernels.py:112-168 recomputed on the fly (no dK matrix in HBM).
+ * grad_out (doubles): [0] d/dk_scale | n_length entries d/dk_length | n_period entries d/dk_period
+ * (periodic kernel only) | 1 entry d/dk_noise (0 unless apply_noise and n_noise == 1; a per-point
+ * noise vector is data).  k_length / k_period with one entry get the derivative summed over dimensions.
+ * alpha_out optional (n,) = K^-1 r = d logp / d mean(x).  Caches L and z like gpx_fit_predict.
+ * Returns info like gpx_fit_factor (info > 0: NaN outputs). */
+int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const double* y_minus_m, double* logp,
+                 double* grad_out, double* alpha_out);
+
 /* _get_mean_and_covariance (gpax/gp.py:247-312, Cholesky branch :295-301) at the
  * resident x_new with the cached factor and the y_minus_m of the last
  * gpx_log_marginal:  mean = m_new + k_cross K^-1 r,  cov = k_new - k_cross K^-1 k_cross^T,

@@ -17,16 +17,22 @@ def _dummy_sinusoidal_data():
     return x.reshape(-1, 1), y.squeeze(), np.linspace(-1.1, 1.1, 300).reshape(-1, 1)
 
 
+@pytest.mark.parametrize("gp_factory", ["ExactGP", "VariationalInferenceGP"])
 @pytest.mark.parametrize("y_std", [None, 0.0, 1.0])
 @pytest.mark.parametrize("model_state", ["unconditioned_prior", "prior", "posterior"])
-def test_ExactGP_sample_shapes(y_std, model_state):
-    """gpax/_tests/test_gp.py:8-47 for ExactGP x RBFKernel."""
+def test_ExactGP_sample_shapes(gp_factory, y_std, model_state):
+    """gpax/_tests/test_gp.py:8-47: {ExactGP, VariationalInferenceGP} x RBFKernel."""
+    from gpax_amd import gp as gp_mod
     from gpax_amd import state
-    from gpax_amd.gp import ExactGP
     from gpax_amd.kernels import RBFKernel
 
     HP_SAMPLES, GP_SAMPLES = 17, 33
-    kwargs = {"hp_samples": HP_SAMPLES, "gp_samples": GP_SAMPLES, "num_warmup": 100}
+    if gp_factory == "ExactGP":
+        kwargs = {"hp_samples": HP_SAMPLES, "gp_samples": GP_SAMPLES, "num_warmup": 100}
+    else:   # gpax/_tests/test_gp.py:23-31: VI uses the guide median only
+        HP_SAMPLES = 1
+        kwargs = {"hp_samples": HP_SAMPLES, "gp_samples": GP_SAMPLES, "num_steps": 10}
+    ExactGP = getattr(gp_mod, gp_factory)
     x, y, x_grid = _dummy_sinusoidal_data()
     x_grid = x_grid[::5]
     state.set_rng_key(0)
@@ -41,7 +47,6 @@ def test_ExactGP_sample_shapes(y_std, model_state):
         gp = ExactGP(kernel=kernel, x=x, y=y, y_std=y_std, **kwargs)
     else:
         gp = ExactGP(kernel=kernel, x=x, y=y, y_std=y_std, **kwargs)
-        gp.mcmc_run_kwargs = {"num_leapfrog": 4}
         gp.fit()
     result = gp.sample(x_grid)
     yy = result.y
@@ -124,9 +129,9 @@ def test_fit_recovers_noise_scale():
     x = np.sort(rng.uniform(-1, 1, 60)).reshape(-1, 1)
     y = np.sin(4 * x[:, 0]) + 0.1 * rng.standard_normal(60)
     state.set_rng_key(1)
-    gp = ExactGP(kernel=RBFKernel(k_noise=Parameter(HalfNormal(0.1), 1)), x=x, y=y, hp_samples=60, num_warmup=150,
-                 mcmc_run_kwargs={"num_leapfrog": 6})
+    gp = ExactGP(kernel=RBFKernel(k_noise=Parameter(HalfNormal(0.1), 1)), x=x, y=y, hp_samples=60, num_warmup=150)
     gp.fit()
+    assert gp.metadata["mcmc_info"][0]["divergences"] <= 3
     hp, n = gp._get_hp_samples_from_posterior(False)
     assert n == 60 and set(hp) == {"k_noise", "k_scale", "k_length"}
     noise_med = float(np.median(hp["k_noise"]))

@@ -150,3 +150,80 @@ def test_param_space_bijection():
     p, lp = sp.unpack(u0)
     assert p["k_scale"][0] == pytest.approx(1.0) and p["k_noise"][0] == pytest.approx(orc.K_NOISE_MEDIAN)
     assert p["k_jitter"][0] == 1e-6 and np.isfinite(lp)
+
+
+# ------------------------------------------------------------------ samplers and prior gradients (host only)
+
+
+def test_prior_grad_terms_match_central_differences():
+    from gpax_amd.utils.prior_utils import HalfNormal, LogNormal, Normal, Uniform
+
+    u, h = np.array([-0.7, 0.4, 1.3]), 1e-6
+    for dist in (HalfNormal(0.5), LogNormal(0.3, 1.2), Uniform(1.0, 3.0), Normal(0.5, 2.0)):
+        def f(v):
+            x, lj = dist.from_unconstrained(v)
+            return dist.log_prob(x) + lj
+
+        x, dx, g = dist.grad_terms(u)
+        assert np.allclose(x, dist.from_unconstrained(u)[0])
+        assert np.allclose(g, (f(u + h) - f(u - h)) / (2 * h), atol=1e-6)
+        assert np.allclose(dx, (dist.from_unconstrained(u + h)[0] - dist.from_unconstrained(u - h)[0]) / (2 * h), atol=1e-7)
+        assert np.allclose(dist.to_unconstrained(x), u)
+
+
+def test_warmup_windows_follow_the_stan_schedule():
+    from gpax_amd import mcmc
+
+    assert mcmc._windows(10) == []
+    assert mcmc._windows(1000) == [(75, 100), (100, 150), (150, 250), (250, 450), (450, 950)]
+    w = mcmc._windows(100)
+    assert w[0][0] == 15 and w[-1][1] == 90 and all(a < b for a, b in w)
+
+
+@pytest.mark.parametrize("algorithm", ["nuts", "hmc"])
+def test_sampler_recovers_a_badly_scaled_gaussian(algorithm):
+    from gpax_amd import mcmc
+
+    sd, mu = np.array([0.1, 1.0, 10.0]), np.array([1.0, -2.0, 0.5])
+
+    def vg(u):
+        z = (u - mu) / sd
+        return -0.5 * float(z @ z), -z / sd
+
+    draws, info = mcmc.sample(vg, np.zeros(3), 500, 3000, np.random.default_rng(1), algorithm=algorithm, num_leapfrog=12)
+    assert draws.shape == (3000, 3) and info["divergences"] == 0
+    assert np.all(np.abs(draws.mean(0) - mu) < 0.25 * sd)
+    assert np.all(np.abs(draws.std(0) / sd - 1.0) < 0.15)
+    assert np.allclose(info["inverse_mass"], sd**2, rtol=0.5)       # the mass matrix adapted to the scales
+
+
+def test_nuts_is_unbiased_on_a_skewed_target():
+    """u = log Gamma(3): mean digamma(3), variance trigamma(3)."""
+    from scipy.special import polygamma
+
+    from gpax_amd import mcmc
+
+    def vg(u):
+        return float(np.sum(3 * u - np.exp(u))), 3 - np.exp(u)
+
+    draws, info = mcmc.sample(vg, np.zeros(2), 500, 6000, np.random.default_rng(8))
+    assert np.all(np.abs(draws.mean(0) - polygamma(0, 3)) < 0.05)
+    assert np.all(np.abs(draws.var(0) - polygamma(1, 3)) < 0.05)
+    assert 0.7 < info["mean_accept"] < 0.98
+
+
+def test_sampler_rejects_bad_arguments():
+    from gpax_amd import mcmc
+
+    with pytest.raises(ValueError):
+        mcmc.sample(lambda u: (0.0, np.zeros(1)), np.zeros(1), 5, 5, np.random.default_rng(0), algorithm="gibbs")
+    with pytest.raises(ValueError):
+        mcmc.sample(lambda u: (-np.inf, np.zeros(1)), np.zeros(1), 5, 5, np.random.default_rng(0))
+
+
+def test_adam_matches_the_textbook_update():
+    from gpax_amd.gp import _Adam
+
+    opt = _Adam(2, step_size=0.1, b1=0.5, b2=0.9)
+    x = opt.step(np.zeros(2), np.array([1.0, -2.0]))
+    assert np.allclose(x, [0.1, -0.1], atol=1e-6)       # first step: m_hat / sqrt(v_hat) = sign(grad)

@@ -254,3 +254,39 @@ def test_golden_inverse_branch_gap_recorded():
     g = load_golden("sin25_rbf")
     assert np.abs(g["post_mean"] - g["post_mean_inv"]).max() < 1e-6
     assert np.nanmax(np.abs(g["post_sd"] - g["post_sd_inv"])) < 1e-4
+
+
+# ---------------------------------------------------------------- gradient of the log-marginal
+
+
+@pytest.mark.parametrize("kind", [orc.RBF, orc.MATERN52, orc.PERIODIC])
+@pytest.mark.parametrize("ard", [False, True])
+def test_lml_grad_matches_central_differences(kind, ard):
+    """The oracle's closed-form gradient (the checker of gpx_lml_grad) against central differences of the
+    oracle's own log-marginal -- the only pin available: the reference obtains this by jax.grad and holds no
+    numbers for it (parity unpinned)."""
+    rng = np.random.default_rng(3 + kind)
+    n, d = 40, 3
+    x, r = rng.uniform(-1, 1, (n, d)), rng.standard_normal(n)
+    kl = rng.uniform(0.5, 1.5, d) if ard else np.array([0.8])
+    kp = (rng.uniform(1.5, 2.5, d) if ard else np.array([2.0])) if kind == orc.PERIODIC else None
+    s, nz, h = 1.3, 0.05, 1e-6
+
+    def f(s=s, kl=kl, kp=kp, nz=nz):
+        return orc.mvn_log_prob(r, np.zeros(n), orc.gram(kind, x, x, s, kl, kp, nz, 1e-6, True))[0]
+
+    logp, g, alpha = orc.lml_grad(kind, x, r, s, kl, kp, nz)
+    assert abs(logp - f()) < 1e-10
+    assert np.allclose(alpha, np.linalg.solve(orc.gram(kind, x, x, s, kl, kp, nz, 1e-6, True), r), rtol=1e-8)
+    assert abs((f(s=s + h) - f(s=s - h)) / (2 * h) - g["k_scale"][0]) < 1e-5
+    assert abs((f(nz=nz + h) - f(nz=nz - h)) / (2 * h) - g["k_noise"][0]) < 1e-4
+    for i in range(kl.size):
+        e = np.zeros_like(kl)
+        e[i] = h
+        assert abs((f(kl=kl + e) - f(kl=kl - e)) / (2 * h) - g["k_length"][i]) < 1e-5
+    if kind == orc.PERIODIC:
+        for i in range(kp.size):
+            e = np.zeros_like(kp)
+            e[i] = h
+            assert abs((f(kp=kp + e) - f(kp=kp - e)) / (2 * h) - g["k_period"][i]) < 1e-5
+    assert g["k_length"].shape == kl.shape
