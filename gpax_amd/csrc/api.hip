@@ -136,7 +136,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_NB"))) h->nb = atoi(env) == 64 ? 64 : 128;
   if ((env = getenv("GPX_LOOKAHEAD"))) h->lookahead = atoi(env) != 0;
   if ((env = getenv("GPX_GRAPH"))) h->use_graph = atoi(env) != 0;
-  if ((env = getenv("GPX_DEPTH"))) h->depth = atoi(env) >= 2 ? 2 : 1;
+  if ((env = getenv("GPX_DEPTH"))) h->depth = std::min(std::max(atoi(env), 1), 3);
   *out = h;
   return GPX_OK;
 }
@@ -148,13 +148,14 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   gpx_dist_free(h);
   void* bufs[] = {h->d_x, h->d_xnew, h->d_r, h->d_mnew, h->d_hyp, h->d_noise, h->d_A, h->d_L, h->d_W,
                   h->d_S, h->d_cov, h->d_z, h->d_scal, h->d_info, h->d_mean, h->d_g1, h->d_g2,
-                  h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2, h->d_kinv, h->d_gpart};
+                  h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2, h->d_kinv, h->d_gpart, h->d_mini};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
   for (auto e : h->ev_far) (void)hipEventDestroy(e);
+  for (auto e : h->ev_w) (void)hipEventDestroy(e);
   for (auto e : h->ev_panel) (void)hipEventDestroy(e);
   for (auto e : h->ev_trail) (void)hipEventDestroy(e);
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
@@ -191,7 +192,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "lookahead")) { h->lookahead = value != 0; return GPX_OK; }
   if (!strcmp(name, "graph")) { h->use_graph = value != 0; return GPX_OK; }
-  if (!strcmp(name, "depth")) { h->depth = value >= 2 ? 2 : 1; return GPX_OK; }
+  if (!strcmp(name, "depth")) { h->depth = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 3); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -355,23 +356,42 @@ extern "C" int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const dou
 
 // ------------------------------------------------------------- bordered factorisation
 
+// Events that only order work between the handle's own streams on one device: a device-scope
+// release is all they need; the default system-scope fence of an event record costs the NEXT kernel of the
+// recording stream ~8 us (measured: 2.24 -> 2.12 ms per N=4096 step with hipEventDisableSystemFence).  Results
+// reach the host through stream-ordered copies, which carry their own fences.
+static unsigned sync_event_flags() {
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("GPX_EVENT_MODE"); mode = e ? atoi(e) : 2; }
+  unsigned f = hipEventDisableTiming;
+  if (mode == 1) f |= hipEventReleaseToDevice;
+  if (mode == 2) f |= hipEventDisableSystemFence;
+  return f;
+}
+
 static int ensure_events(gpx_handle* h, size_t nblk) {
-  if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-  if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+  const unsigned fl = sync_event_flags();
+  if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, fl));
+  if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
   while (h->ev_far.size() < nblk) {
-    hipEvent_t a;
-    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming));
+    hipEvent_t a, b;
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, fl));
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, fl));
     h->ev_far.push_back(a);
+    h->ev_w.push_back(b);
   }
+  GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, (int64_t)h->nb * h->nb));
   while (h->ev_panel.size() < nblk) {
     hipEvent_t a, b;
-    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming));
-    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, hipEventDisableTiming));
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, fl));
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, fl));
     h->ev_panel.push_back(a);
     h->ev_trail.push_back(b);
   }
   return GPX_OK;
 }
+
+static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base);
 
 // Right-looking blocked Cholesky of the (npad x npad) matrix in d_A with `rows - npad`
 // border rows riding along (they are only ever "rows below the panel").  Results in d_L.
@@ -391,6 +411,7 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
 // U = L^-T); border block j is still all-zero in the panels k < j, so step k only carries rows
 // below tri_base + (k+1)*nb -- the triangular inverse costs N^3/3 flops instead of N^3.
 static int factor_loop(gpx_handle* h, int64_t rows_total, int64_t tri_base = -1) {
+  if (h->lookahead != 0 && h->depth >= 3) return factor_loop_split(h, rows_total, tri_base);
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld;
   const int64_t nblk = npad / nb;
   const bool la = h->lookahead != 0;
@@ -475,6 +496,125 @@ static int factor_loop(gpx_handle* h, int64_t rows_total, int64_t tri_base = -1)
       GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));
       GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join2, 0));
     }
+  }
+  return GPX_OK;
+}
+
+// Split-panel schedule (depth 3).  The chain stream P carries ONLY what the next diagonal block needs:
+//   P:  potrf(k) -> S = A_{k+1,k} W_k^T (one block row of the panel, 16 workgroups, into scratch)
+//                -> A_{k+1,k+1} -= S S^T (10 workgroups) -> potrf(k+1) ...
+//   Q:  the full panel k (all rows, incl. block row k+1 again: the official L) -> update of columns k+1
+//       (below its diagonal block) and k+2 by panel k
+//   T:  bulk update of the columns >= k+3
+// so the big panel GEMM (which runs 2-3x slower while the bulk kernel owns the CUs) and one
+// cross-stream hand-over leave the critical path: per block column it is potrf + two ~6 us kernels.
+// Hand-overs (each an event): W_k P->Q; panel k Q->T; columns k+1,k+2 Q->P (needed by S of step k+1:
+// a whole diagonal block later); column k+2 T->Q (bulk of step k-1).  One writer per block at a time:
+// block (k+1,k+1) belongs to P at step k (Q's column-k+1 update starts below it).
+static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base) {
+  const int64_t nb = h->nb, npad = h->npad, ld = h->ld, nblk = npad / nb;
+  hipStream_t P = h->s_main, Q = h->s_far, T = h->s_trail;
+  double* A = h->d_A; double* L = h->d_L; double* S = h->d_mini;
+  std::vector<char> q_pending((size_t)nblk, 0), t_pending((size_t)nblk, 0);
+  auto rows_at = [&](int64_t k) -> int64_t {
+    return tri_base >= 0 ? std::min<int64_t>(rows_total, tri_base + (k + 1) * nb) : rows_total;
+  };
+  bool q_used = false, t_used = false;
+  for (int64_t k = 0; k < nblk; ++k) {
+    const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
+    prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
+    GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
+                              h->d_info, (int)c0));
+    prof_end(h, P);
+    const int64_t mrows = rows - r0;
+    if (mrows <= 0) continue;
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
+
+    // ---- Q: the whole panel
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
+    q_used = true;
+    {
+      GemmLaunch g;
+      g.A = A + r0 * ld + c0; g.lda = ld;
+      g.B = h->d_W + k * nb * nb; g.ldb = nb;
+      g.C = L + r0 * ld + c0; g.ldc = ld;
+      g.M = mrows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+      g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+      prof_begin(h, Q, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
+      GPX_RET(launch_gemm_nt(h, Q, g));
+      prof_end(h, Q);
+    }
+    if (k + 1 >= nblk) continue;   // border rows only: nothing left to update
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
+
+    // ---- P: the diagonal band
+    if (k >= 1 && q_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
+    {
+      GemmLaunch g;
+      g.A = A + r0 * ld + c0; g.lda = ld;
+      g.B = h->d_W + k * nb * nb; g.ldb = nb;
+      g.C = S; g.ldc = nb;
+      g.M = nb; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+      g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+      prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
+      GPX_RET(launch_gemm_nt(h, P, g));
+      prof_end(h, P);
+      GemmLaunch u;
+      u.A = S; u.lda = nb; u.B = S; u.ldb = nb;
+      u.C = A + r0 * ld + r0; u.ldc = ld;
+      u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
+      u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
+      prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
+      GPX_RET(launch_gemm_nt(h, P, u));
+      prof_end(h, P);
+    }
+
+    // ---- Q: columns k+1 (below its diagonal block) and k+2, rows from block row k+2 down
+    const int64_t rr = (k + 2) * nb, mr = rows - rr;
+    const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
+    if (mr > 0) {
+      if (k >= 1 && t_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)(k - 1)], 0));
+      GemmLaunch t;
+      t.A = L + rr * ld + c0; t.lda = ld;
+      t.B = L + r0 * ld + c0; t.ldb = ld;
+      t.C = A + rr * ld + r0; t.ldc = ld;
+      t.M = mr; t.N = ncb * nb; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
+      t.lower = 1; t.row_off = rr; t.col_off = r0; t.b_lower_tri = 0; t.small_tile = 1;
+      const double entries = (double)mr * nb + (ncb > 1 ? (double)nb * (nb + 1) / 2.0 + (double)(mr - nb) * nb : 0.0);
+      prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(mr + ncb * nb) * nb));
+      GPX_RET(launch_gemm_nt(h, Q, t));
+      prof_end(h, Q);
+    }
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
+    q_pending[(size_t)k] = 1;
+
+    // ---- T: bulk, columns >= k+3
+    const int64_t nbulk = nblk - (k + 3);
+    if (nbulk > 0) {
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
+      t_used = true;
+      const int64_t cf = k + 3, br = cf * nb, bm = rows - br, nc = nbulk * nb;
+      GemmLaunch t;
+      t.A = L + br * ld + c0; t.lda = ld;
+      t.B = L + br * ld + c0; t.ldb = ld;
+      t.C = A + br * ld + br; t.ldc = ld;
+      t.M = bm; t.N = nc; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
+      t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
+      const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
+      prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * nb, 8.0 * (2.0 * entries + (double)(bm + nc) * nb));
+      GPX_RET(launch_gemm_nt(h, T, t));
+      prof_end(h, T);
+      GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
+      t_pending[(size_t)k] = 1;
+    }
+  }
+  if (t_used) {
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
+  }
+  if (q_used) {
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join2, 0));
   }
   return GPX_OK;
 }

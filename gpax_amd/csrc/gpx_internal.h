@@ -148,7 +148,7 @@ struct gpx_handle {
   // options
   int nb = 128;
   int lookahead = 1;
-  int depth = 2;       // look-ahead depth: 1 = classic, 2 = far look-ahead column on a third stream
+  int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
   // resident inputs
@@ -201,7 +201,8 @@ struct gpx_handle {
   // events for the two-stream lookahead
   std::vector<hipEvent_t> ev_panel, ev_trail;
   hipEvent_t ev_join = nullptr, ev_join2 = nullptr;
-  std::vector<hipEvent_t> ev_far;
+  std::vector<hipEvent_t> ev_far, ev_w;
+  double* d_mini = nullptr; int64_t mini_cap = 0;   // nb x nb scratch of the split-panel schedule (L_{k+1,k} for the chain)
 
   DistState dist;
 

@@ -79,10 +79,11 @@ def test_factor_lml_posterior_match_golden(core, name, nb):
     assert np.abs(var - np.diag(g["post_cov"])).max() <= TOL_POST
 
 
-@pytest.mark.parametrize("lookahead", [0, 1, 2])
+@pytest.mark.parametrize("lookahead", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_fused_fit_predict_matches_golden(core, name, lookahead):
-    """lookahead 0: one stream; 1: classic look-ahead (two streams); 2: depth-2 (three streams)."""
+    """lookahead 0: one stream; 1: classic look-ahead (two streams); 2: depth-2 (three streams); 3: split panel
+    (the default: the chain stream carries only the diagonal band)."""
     g = load_golden(name)
     core.set_option("nb", 128)
     core.set_option("lookahead", 1 if lookahead else 0)
@@ -91,7 +92,7 @@ def test_fused_fit_predict_matches_golden(core, name, lookahead):
     core.set_test(g["x_new"])
     info, logp, mean, var = core.fit_predict(_params(g), g["y"] - g["m_train"], g["m_new"], _new_noise(g))
     core.set_option("lookahead", 1)
-    core.set_option("depth", 2)
+    core.set_option("depth", 3)
     assert info == 0
     assert abs(logp - float(g["logp"])) <= TOL_LOGP_REL * abs(float(g["logp"]))
     scale = max(1.0, np.abs(g["post_mean"]).max())
@@ -176,7 +177,7 @@ def test_against_oracle_seeded(core, n, d, kind):
     assert np.abs(l - orc.cholesky_lower(k_ref)).max() <= TOL_L
 
 
-@pytest.mark.parametrize("depth", [1, 2])
+@pytest.mark.parametrize("depth", [1, 2, 3])
 def test_lookahead_schedules_are_deterministic(core, depth):
     """No tile is ever updated by two streams at once: repeated runs of the multi-stream schedules
     at N=2000 (16 panels, ragged) are bit-identical, and agree with the one-stream schedule and the
@@ -196,7 +197,7 @@ def test_lookahead_schedules_are_deterministic(core, depth):
     for _ in range(4):
         _, _, l = core.fit_factor(prm, want_l=True)
         assert np.array_equal(l, l0)
-    core.set_option("depth", 2)
+    core.set_option("depth", 3)
     assert np.abs(l0 - l_ref).max() <= 1e-12
     assert np.abs(l0 - orc.cholesky_lower(orc.rbf(x, x, 1.0, 1.0, p["k_noise"], 1e-6))).max() <= TOL_L
 
