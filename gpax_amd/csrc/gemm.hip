@@ -29,6 +29,8 @@ struct GemmArgs {
   int64_t row_off, col_off;
   int lower, b_lower_tri;
   int a_upper_tri;   // A[m][k] == 0 for k < m (rows of an upper-triangular factor): K below the tile's first row is dead
+  // XCD-aware 1-D tile map of the lower trapezoid (map_S > 0; row_off == col_off): see tile_from_block()
+  int map_S; int64_t map_nti, map_ntj, map_nsj, map_nsuper;
   // block-cyclic row distribution (distributed factorisation): local row m is global row
   // ((m / cyc_nb) * cyc_P + cyc_r) * cyc_nb + m % cyc_nb;  cyc_P <= 1: rows are global already
   int cyc_P, cyc_r, cyc_nb;
@@ -40,6 +42,16 @@ __device__ __forceinline__ int64_t tile_global_row(const GemmArgs& g, int64_t m0
   if (g.cyc_P > 1) r = ((r / g.cyc_nb) * g.cyc_P + g.cyc_r) * g.cyc_nb + r % g.cyc_nb;
   return r;
 }
+
+// Lower-trapezoid tile for a 1-D grid, XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs (private
+// L2 each) by linear id, so with the plain 2-D grid every XCD streams the WHOLE panel through its L2 (measured:
+// 43 MB of panel fetches beside 36 MB of C per launch at N=4096).  Here the id is read as (XCD label x = id % 8,
+// sequence number id / 8): XCD label x works through the S x S-tile super-tiles x, x+8, x+16, ... of the lower
+// trapezoid, S*S consecutive sequence numbers each, so the tiles resident on one XCD at a time share S tile rows
+// of A and S tile rows of B (panel traffic ~2/S of the C traffic), and no workgroup is spent on tiles above the
+// diagonal except inside the diagonal super-tiles.  Returns false for an empty slot.  Placement is a speed
+// matter only: every tile is computed exactly once whatever XCD it lands on.
+__device__ __forceinline__ bool tile_from_block(const struct GemmArgs& g, int64_t& ti, int64_t& tj);
 
 #define GEMM_BK 32
 #define GEMM_LDT (GEMM_BK + 4)
@@ -55,6 +67,29 @@ __device__ unsigned long long* g_gemm_stamps;
 #define GEMM_STAMP(slot) do { } while (0)
 #endif
 
+__device__ __forceinline__ bool tile_from_block(const GemmArgs& g, int64_t& ti, int64_t& tj) {
+  const int64_t b = blockIdx.x;
+  const int x = (int)(b & 7);
+  const int64_t seq = b >> 3;
+  const int S = g.map_S, S2 = S * S;
+  const int64_t u = (seq / S2) * 8 + x;
+  const int slot = (int)(seq % S2);
+  if (u >= g.map_nsuper) return false;
+  const int64_t nsj = g.map_nsj, ntri = nsj * (nsj + 1) / 2;
+  int64_t si, sj;
+  if (u < ntri) {   // row si of the triangular part holds si + 1 super-tiles
+    si = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
+    while (si * (si + 1) / 2 > u) --si;
+    while ((si + 1) * (si + 2) / 2 <= u) ++si;
+    sj = u - si * (si + 1) / 2;
+  } else {
+    const int64_t v = u - ntri;
+    si = nsj + v / nsj; sj = v % nsj;
+  }
+  ti = si * S + slot / S; tj = sj * S + slot % S;
+  return ti < g.map_nti && tj < g.map_ntj && tj <= ti;
+}
+
 template <int BM, int BN>
 // (256, 2): a register budget of 256 makes hipcc keep the accumulators in VGPRs.  With the default budget it
 // puts them in AGPRs, and v_mfma_f64_16x16x4_f64 with an AGPR accumulator issues every ~100 cycles instead of
@@ -68,8 +103,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-  if (g.lower && (tile_global_row(g, m0) + BM - 1 < g.col_off + n0)) return;  // tile strictly above the diagonal
+  int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  if (g.map_S > 0) {
+    int64_t ti, tj;
+    if (!tile_from_block(g, ti, tj)) return;
+    m0 = ti * BM; n0 = tj * BN;
+  } else if (g.lower && (tile_global_row(g, m0) + BM - 1 < g.col_off + n0)) {
+    return;  // tile strictly above the diagonal
+  }
 
   int64_t kend = g.K;
   if (g.b_lower_tri) {  // B[n][k] == 0 for k > n: K beyond the tile's last row is dead
@@ -78,23 +119,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   }
 
   const int fr = lane & 15, fk = lane >> 4;
-  // The C tile is loaded FIRST, straight into the accumulators (its latency hides under the first
-  // A/B tile loads), pre-scaled so that the epilogue is a pure store:
-  //   beta*C + alpha*sum = alpha * (sum + (beta/alpha)*C)      (alpha = +-1 on every call site)
-  v4d acc[TM][TN];
-  const double cscale = g.beta / g.alpha;
+  v4d acc[TM][TN], cin[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      if (g.beta != 0.0) {
-        const double* cp = g.C + (m0 + wm * (BM / 2) + i * 16 + fk) * g.ldc + n0 + wn * (BN / 2) + j * 16 + fr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = cscale * cp[(int64_t)(4 * r) * g.ldc];
-      } else {
-        acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0};
-      }
-    }
+    for (int j = 0; j < TN; ++j) { acc[i][j] = (v4d){0.0, 0.0, 0.0, 0.0}; cin[i][j] = (v4d){0.0, 0.0, 0.0, 0.0}; }
 
   v2d ra[NA], rb[NBc];
   const double* Ag = g.A + m0 * g.lda;
@@ -131,6 +160,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
   const int64_t kbeg = g.a_upper_tri ? (m0 / GEMM_BK) * GEMM_BK : 0;
   GEMM_STAMP(0);
   load_tiles(kbeg);
+  // The C tile (an HBM miss: it is streamed, read once per launch) is requested AFTER the first A/B chunk
+  // (L2 hits) and consumed only in the epilogue.  Loads return in order, so the first LDS store waits for the
+  // A/B chunk alone and the C latency hides behind the first chunk's MFMAs instead of in front of them
+  // (stamps: the first chunk took 7-8k cycles against 2.5k for the others when C initialised the accumulators).
+  if (g.beta != 0.0) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const double* cp = g.C + (m0 + wm * (BM / 2) + i * 16 + fk) * g.ldc + n0 + wn * (BN / 2) + j * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cin[i][j][r] = cp[(int64_t)(4 * r) * g.ldc];
+      }
+  }
   for (int64_t k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
     store_tiles();
     GEMM_STAMP(1 + 3 * (int)(k0 / GEMM_BK));
@@ -169,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + wm * (BM / 2) + i * 16 + fk + 4 * r;
-        g.C[row * g.ldc + col] = g.alpha * acc[i][j][r];
+        g.C[row * g.ldc + col] = fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]);
       }
     }
 }
@@ -372,6 +415,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   }
 }
 
+static bool gemm_tile_map_enabled() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("GPX_TILE_MAP"); on = e ? atoi(e) : 0; }
+  return on != 0;
+}
+
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   if (L.M <= 0 || L.N <= 0) return GPX_OK;
   const int bm = L.small_tile ? 32 : 64;
@@ -386,6 +435,7 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   g.a_upper_tri = L.a_upper_tri;
+  g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
   if (L.a_upper_tri && (L.small_tile || L.variant != 0)) {
     gpx_set_error(h, "gemm_nt: a_upper_tri is served by the 64x64 kernel only");
     return GPX_ERR_ARG;
@@ -404,6 +454,25 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   if (!L.small_tile && L.variant == 2 && L.M % 128 == 0 && L.N % 128 == 0) {
     dim3 g128((unsigned)(L.N / 128), (unsigned)(L.M / 128));
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), g128, dim3(256), 0, s, g);
+    GPX_HIP_CHECK(h, hipGetLastError());
+    return GPX_OK;
+  }
+  if (!L.small_tile && L.variant == 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && gemm_tile_map_enabled()) {
+    const int64_t nti = L.M / 64, ntj = L.N / 64;
+    int S = 1;
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("GPX_TILE_S"); forced = e ? atoi(e) : 0; }
+    if (forced > 0) S = forced;
+    else for (int cand : {8, 4, 2}) {
+      const int64_t nsj = (ntj + cand - 1) / cand, nsi = (nti + cand - 1) / cand;
+      if (nsj * (nsj + 1) / 2 + (nsi - nsj) * nsj >= 32) { S = cand; break; }
+    }
+    g.map_S = S; g.map_nti = nti; g.map_ntj = ntj;
+    g.map_nsj = (ntj + S - 1) / S;
+    const int64_t nsi = (nti + S - 1) / S;
+    g.map_nsuper = g.map_nsj * (g.map_nsj + 1) / 2 + (nsi - g.map_nsj) * g.map_nsj;
+    const int64_t rounds = (g.map_nsuper + 7) / 8;
+    hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)(rounds * 8 * S * S)), dim3(256), 0, s, g);
     GPX_HIP_CHECK(h, hipGetLastError());
     return GPX_OK;
   }

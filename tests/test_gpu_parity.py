@@ -202,6 +202,32 @@ def test_lookahead_schedules_are_deterministic(core, depth):
     assert np.abs(l0 - orc.cholesky_lower(orc.rbf(x, x, 1.0, 1.0, p["k_noise"], 1e-6))).max() <= TOL_L
 
 
+@pytest.mark.parametrize("pair_min", [0, 1, 6, 13])
+def test_paired_bulk_updates_match_the_oracle(core, pair_min):
+    """The split-panel schedule pairs the bulk updates (panels k-1, k in one K = 2 nb pass at odd k) while more
+    than pair_min block columns remain and continues unpaired from the next even k: every switch point, the
+    always-paired case and the never-paired case give the same factor, posterior and log-marginal."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, y, xn, p = orc.synthetic_problem(1333, 5, 77, seed=13)      # 21 panels of 64, ragged
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    core.set_option("nb", 64)
+    core.set_option("pair_min", pair_min)
+    core.set_train(x)
+    core.set_test(xn)
+    _, _, l = core.fit_factor(prm, want_l=True)
+    info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(77), 0.0)
+    core.set_option("nb", 128)
+    core.set_option("pair_min", 32)
+    assert info == 0
+    k_ref = orc.rbf(x, x, p["k_scale"], p["k_length"], p["k_noise"], p["k_jitter"])
+    assert np.abs(l - orc.cholesky_lower(k_ref)).max() <= TOL_L
+    logp_ref, mean_ref, var_ref = orc.fit_predict(orc.RBF, x, y, xn, p)
+    assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+    assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
+
+
 def test_full_size_properties(core):
     """BASELINE config C2 (N=4096, d=8, RBF, M=1000) through size-independent properties:
     K symmetric, L L^T = K, logp and posterior against the oracle (LAPACK, ~1 s)."""
