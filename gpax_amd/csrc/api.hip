@@ -138,6 +138,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_GRAPH"))) h->use_graph = atoi(env) != 0;
   if ((env = getenv("GPX_DEPTH"))) h->depth = std::min(std::max(atoi(env), 1), 3);
   if ((env = getenv("GPX_PAIR_MIN"))) h->pair_min = std::max(atoi(env), 0);
+  if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
   *out = h;
   return GPX_OK;
 }
@@ -195,6 +196,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "graph")) { h->use_graph = value != 0; return GPX_OK; }
   if (!strcmp(name, "depth")) { h->depth = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 3); return GPX_OK; }
   if (!strcmp(name, "pair_min")) { h->pair_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
+  if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -206,6 +208,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "graph")) { *value = h->use_graph; return GPX_OK; }
   if (!strcmp(name, "depth")) { *value = h->depth; return GPX_OK; }
   if (!strcmp(name, "pair_min")) { *value = h->pair_min; return GPX_OK; }
+  if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -523,17 +526,24 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     return tri_base >= 0 ? std::min<int64_t>(rows_total, tri_base + (k + 1) * nb) : rows_total;
   };
   bool q_used = false, t_used = false;
-  // Paired bulk updates while the factorisation is bulk-bound (more than `pair_min` block columns left): T applies
-  // panels {k-1, k} in ONE K = 2 nb pass at odd k, halving the read-modify-write passes over the trailing matrix
-  // (N = 16384: 42.0 -> 36.9 ms).  In the chain-bound tail it would put the double-length kernel one step
-  // before its consumer (N = 4096 all-paired: 1.99 -> 2.11 ms), so from the first even k with fewer columns
-  // left the schedule continues unpaired; after any odd paired step every column >= k+3 is current through
-  // panel k, which is exactly the unpaired invariant, so the switch needs no fix-up.
-  const int64_t pair_min = h->pair_min;
-  int64_t k_switch = 0;   // first unpaired step (even)
-  if (pair_min > 0) while (k_switch + 2 <= nblk && nblk - k_switch > pair_min) k_switch += 2;
+  // Grouped bulk updates while the factorisation is bulk-bound: T applies the g most recent panels in ONE
+  // K = g nb pass every g-th step, cutting the read-modify-write passes over the trailing matrix g-fold (the bulk
+  // kernel spends about as long on a tile's C traffic as on 128 columns of MFMA work; N = 16384: 42.0 ms with
+  // g = 1, 36.4 with g = 2).  g is chosen per group from the block columns still to go: 4 above `quad_min`,
+  // 2 above `pair_min`, else 1 -- in the chain-bound tail a g-fold kernel would sit one step before its
+  // consumer (N = 4096 with g = 2 throughout: 1.99 -> 2.11 ms).  Invariant after T's step j: every column
+  // >= j+3 is current through panel j; Q brings column k+2 up to date with the panels since then, so a change
+  // of g at a group boundary needs no fix-up.
+  const int64_t pair_min = h->pair_min, quad_min = h->quad_min;
+  int64_t last_t = -1;        // last step at which T acted (panels <= last_t are in every column >= last_t+3)
+  int64_t group_end = -1;     // the step at which T acts next
+  int64_t q_waited_t = -1;    // the T step Q has already waited for
   for (int64_t k = 0; k < nblk; ++k) {
-    const bool pair = k < k_switch;
+    if (k > group_end) {
+      const int64_t left = nblk - k;
+      const int64_t g = (quad_min > 0 && left > quad_min) ? 4 : ((pair_min > 0 && left > pair_min) ? 2 : 1);
+      group_end = k + g - 1;
+    }
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
     prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
     GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
@@ -582,16 +592,15 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       prof_end(h, P);
     }
 
-    // ---- Q: columns k+1 (below its diagonal block) and k+2, rows from block row k+2 down.
-    // Paired bulk (pair != 0): T applies panels {k-1, k} together at odd k (K = 2 nb: half the passes over
-    // the trailing matrix), so at odd k column k+2 still lacks panel k-1 and gets both here.
+    // ---- Q: columns k+1 (below its diagonal block; panel k) and k+2 (every panel since T's last step),
+    // rows from block row k+2 down
     const int64_t rr = (k + 2) * nb, mr = rows - rr;
     const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
-    const bool odd = (k & 1) != 0;
     if (mr > 0) {
-      // the last bulk update that touched column k+2 ran at step k-1, or k-2 when T idled at k-1 (paired, even)
-      if (k >= 1 && t_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)(k - 1)], 0));
-      else if (k >= 2 && t_pending[(size_t)(k - 2)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)(k - 2)], 0));
+      if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {   // column k+2 was last written there
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
+        q_waited_t = last_t;
+      }
       auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan) -> int {
         GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= rr, -= panels [kfirst, kfirst+npan)
         t.A = L + rr * ld + kfirst * nb; t.lda = ld;
@@ -607,9 +616,10 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         prof_end(h, Q);
         return rc;
       };
-      if (pair && odd && ncb > 1) {
+      const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
+      if (npan2 > 1 && ncb > 1) {
         GPX_RET(col_update(k + 1, 1, k, 1));
-        GPX_RET(col_update(k + 2, 1, k - 1, 2));
+        GPX_RET(col_update(k + 2, 1, last_t + 1, npan2));
       } else {
         GPX_RET(col_update(k + 1, ncb, k, 1));
       }
@@ -617,25 +627,28 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
     q_pending[(size_t)k] = 1;
 
-    // ---- T: bulk, columns >= k+3 (paired: only at odd k, panels k-1 and k in one K = 2 nb pass)
+    // ---- T: bulk, columns >= k+3, panels last_t+1 .. k in one pass
     const int64_t nbulk = nblk - (k + 3);
-    if (nbulk > 0 && (!pair || odd)) {
-      GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
-      t_used = true;
-      const int64_t kfirst = pair ? k - 1 : k, npan = pair ? 2 : 1;
-      const int64_t cf = k + 3, br = cf * nb, bm = rows - br, nc = nbulk * nb;
-      GemmLaunch t;
-      t.A = L + br * ld + kfirst * nb; t.lda = ld;
-      t.B = L + br * ld + kfirst * nb; t.ldb = ld;
-      t.C = A + br * ld + br; t.ldc = ld;
-      t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-      t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
-      const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
-      prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
-      GPX_RET(launch_gemm_nt(h, T, t));
-      prof_end(h, T);
-      GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
-      t_pending[(size_t)k] = 1;
+    if (k == group_end) {
+      if (nbulk > 0) {
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
+        t_used = true;
+        const int64_t kfirst = last_t + 1, npan = k - last_t;
+        const int64_t cf = k + 3, br = cf * nb, bm = rows - br, nc = nbulk * nb;
+        GemmLaunch t;
+        t.A = L + br * ld + kfirst * nb; t.lda = ld;
+        t.B = L + br * ld + kfirst * nb; t.ldb = ld;
+        t.C = A + br * ld + br; t.ldc = ld;
+        t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
+        t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
+        const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
+        prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
+        GPX_RET(launch_gemm_nt(h, T, t));
+        prof_end(h, T);
+        GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
+        t_pending[(size_t)k] = 1;
+      }
+      last_t = k;
     }
   }
   if (t_used) {
@@ -1149,7 +1162,7 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
     // d_hyp / d_noise / d_r / d_mnew, so the same graph is replayed for every hyper-parameter draw.
     char key[512];
     snprintf(key, sizeof(key), "%d|%d|%lld|%lld|%d|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p", fp.kind, fp.apply_noise,
-             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth + 16 * h->pair_min, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
+             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth + 16 * h->pair_min + 4096 * h->quad_min, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
              (void*)h->d_x, (void*)h->d_xnew, (void*)h->d_r, (void*)(h->have_mnew ? h->d_mnew : nullptr),
              (void*)h->d_hyp, (void*)fp.noise_dev, (void*)h->d_mean, (void*)h->d_z);
     auto it = h->graphs.find(key);

@@ -172,8 +172,9 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
                     double* flops, double* bytes);
 
 /* ---- tuning knobs (ints; unknown names -> GPX_ERR_ARG).  "nb" panel width (64 | 128),
- * "lookahead" 0/1, "depth" 1..3 (3 = split-panel schedule, the default), "pair_min" (pair the bulk
- * updates while more than this many block columns remain; 0 = never), "graph" 0/1. */
+ * "lookahead" 0/1, "depth" 1..3 (3 = split-panel schedule, the default), "pair_min" / "quad_min" (group
+ * the bulk updates two / four panels at a time while more than this many block columns remain; 0 = never),
+ * "graph" 0/1. */
 int gpx_set_option(gpx_handle* h, const char* name, int64_t value);
 int gpx_get_option(gpx_handle* h, const char* name, int64_t* value);
 

@@ -202,11 +202,11 @@ def test_lookahead_schedules_are_deterministic(core, depth):
     assert np.abs(l0 - orc.cholesky_lower(orc.rbf(x, x, 1.0, 1.0, p["k_noise"], 1e-6))).max() <= TOL_L
 
 
-@pytest.mark.parametrize("pair_min", [0, 1, 6, 13])
-def test_paired_bulk_updates_match_the_oracle(core, pair_min):
-    """The split-panel schedule pairs the bulk updates (panels k-1, k in one K = 2 nb pass at odd k) while more
-    than pair_min block columns remain and continues unpaired from the next even k: every switch point, the
-    always-paired case and the never-paired case give the same factor, posterior and log-marginal."""
+@pytest.mark.parametrize("pair_min,quad_min", [(0, 0), (1, 0), (6, 0), (13, 0), (1, 1), (4, 10), (0, 7)])
+def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
+    """The split-panel schedule groups the bulk updates (the last 2 or 4 panels in one K = 2 nb / 4 nb pass)
+    while more than pair_min / quad_min block columns remain: never grouped, always paired, always in fours and
+    several switch points all give the same factor, posterior and log-marginal."""
     import gpax_amd
     from oracle import gp_oracle as orc
 
@@ -214,12 +214,14 @@ def test_paired_bulk_updates_match_the_oracle(core, pair_min):
     prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
     core.set_option("nb", 64)
     core.set_option("pair_min", pair_min)
+    core.set_option("quad_min", quad_min)
     core.set_train(x)
     core.set_test(xn)
     _, _, l = core.fit_factor(prm, want_l=True)
     info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(77), 0.0)
     core.set_option("nb", 128)
     core.set_option("pair_min", 32)
+    core.set_option("quad_min", 48)
     assert info == 0
     k_ref = orc.rbf(x, x, p["k_scale"], p["k_length"], p["k_noise"], p["k_jitter"])
     assert np.abs(l - orc.cholesky_lower(k_ref)).max() <= TOL_L
