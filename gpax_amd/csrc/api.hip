@@ -534,6 +534,12 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   // consumer (N = 4096 with g = 2 throughout: 1.99 -> 2.11 ms).  Invariant after T's step j: every column
   // >= j+3 is current through panel j; Q brings column k+2 up to date with the panels since then, so a change
   // of g at a group boundary needs no fix-up.
+  // Q and T fork from P once up front (inside a stream capture a stream must join from the origin stream
+  // first; joining T through an event recorded on Q crashed hipStreamEndCapture on ROCm 7.2)
+  GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
+  GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
+  GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
+  q_used = t_used = true;
   const int64_t pair_min = h->pair_min, quad_min = h->quad_min;
   int64_t last_t = -1;        // last step at which T acted (panels <= last_t are in every column >= last_t+3)
   int64_t group_end = -1;     // the step at which T acts next
@@ -1166,15 +1172,28 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
              (void*)h->d_x, (void*)h->d_xnew, (void*)h->d_r, (void*)(h->have_mnew ? h->d_mnew : nullptr),
              (void*)h->d_hyp, (void*)fp.noise_dev, (void*)h->d_mean, (void*)h->d_z);
     auto it = h->graphs.find(key);
+    if (it == h->graphs.end() && !h->graph_warm.count(key)) {
+      // first call of a shape runs eagerly: lazy one-time initialisation (code-object loading, first use of the
+      // side streams) inside a stream capture crashed the ROCm 7.2 runtime; the capture happens on the second call
+      h->graph_warm.insert(key);
+      GPX_RET(fit_predict_enqueue(h, fp));
+      factor_commit(h, p, m, true);
+      return GPX_OK;
+    }
     if (it == h->graphs.end()) {
       hipGraph_t graph = nullptr;
+      const bool trace = getenv("GPX_TRACE") != nullptr;
+      if (trace) fprintf(stderr, "[gpx] begin capture\n");
       GPX_HIP_CHECK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
       int rc = fit_predict_enqueue(h, fp);
+      if (trace) fprintf(stderr, "[gpx] enqueue rc=%d, end capture\n", rc);
       hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (trace) fprintf(stderr, "[gpx] end capture: %s\n", hipGetErrorString(ce));
       if (rc != GPX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       if (ce != hipSuccess) { gpx_set_error(h, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return GPX_ERR_HIP; }
       hipGraphExec_t exec = nullptr;
       ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      if (trace) fprintf(stderr, "[gpx] instantiate: %s\n", hipGetErrorString(ce));
       (void)hipGraphDestroy(graph);
       if (ce != hipSuccess) { gpx_set_error(h, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); return GPX_ERR_HIP; }
       if (h->graphs.size() >= 16) {  // bound the cache

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -199,6 +200,7 @@ struct gpx_handle {
 
   // captured hipGraphs of the fused fit+predict step, keyed by shape + buffer addresses
   std::map<std::string, hipGraphExec_t> graphs;
+  std::set<std::string> graph_warm;   // shapes that have run eagerly once (capture starts on the second call)
 
   // events for the two-stream lookahead
   std::vector<hipEvent_t> ev_panel, ev_trail;

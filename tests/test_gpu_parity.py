@@ -123,7 +123,18 @@ def test_graph_replay_tracks_hyperparameters(core):
             assert info == 0
             assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
             assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
+    # a size with bulk updates on the third stream, replayed twice
+    x, y, xn, p = orc.synthetic_problem(1100, 3, 40, seed=12)
+    core.set_train(x)
+    core.set_test(xn)
     core.set_option("graph", 1)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, p)
+    for _ in range(2):
+        info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(40), 0.0)
+        assert info == 0 and abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+        assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
+    core.set_option("graph", 0)
 
 
 def test_gram_edge_shapes(core):
