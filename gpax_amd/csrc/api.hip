@@ -75,6 +75,66 @@ static int prof_collect(gpx_handle* h) {
 
 // -------------------------------------------------------------------- create/destroy
 
+// ---- the result block and its one-copy fetch
+#define GPX_OUT_HEAD 10   // doubles in front of mean: scal[8], then 4 ints of info
+
+// (Re)allocate the result block for `count` doubles of mean + var; the head (scal, info) survives a growth.
+static int ensure_out(gpx_handle* h, int64_t count) {
+  if (h->d_out && h->out_cap >= count) return GPX_OK;
+  double* nw = nullptr;
+  GPX_HIP_CHECK(h, hipMalloc(reinterpret_cast<void**>(&nw), (size_t)(GPX_OUT_HEAD + count) * sizeof(double)));
+  if (h->d_out) {
+    GPX_HIP_CHECK(h, hipDeviceSynchronize());
+    GPX_HIP_CHECK(h, hipMemcpy(nw, h->d_out, GPX_OUT_HEAD * sizeof(double), hipMemcpyDeviceToDevice));
+    (void)hipFree(h->d_out);
+  } else {
+    GPX_HIP_CHECK(h, hipMemset(nw, 0, GPX_OUT_HEAD * sizeof(double)));
+  }
+  h->d_out = nw; h->out_cap = count;
+  h->d_scal = nw; h->d_info = reinterpret_cast<int*>(nw + 8); h->d_mean = nw + GPX_OUT_HEAD; h->d_var = h->d_mean + 1;
+  return GPX_OK;
+}
+
+// One device-to-host copy (into pinned memory) of [scal | info | first `tail` doubles after the head], then a
+// stream sync.  Returns a pointer to the pinned copy: scal at [0], info at ((int*)(p + 8))[0], mean at p + 10.
+static int fetch_block(gpx_handle* h, int64_t tail, const double** out) {
+  const int64_t cnt = GPX_OUT_HEAD + tail;
+  if (h->pinned_cap < cnt) {
+    if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+    h->h_pinned = nullptr; h->pinned_cap = 0;
+    GPX_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_pinned), (size_t)cnt * sizeof(double), hipHostMallocDefault));
+    h->pinned_cap = cnt;
+  }
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->h_pinned, h->d_out, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, h->s_main));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  *out = h->h_pinned;
+  return GPX_OK;
+}
+
+// Host -> device copy of a few doubles through a ring of pinned slots: truly asynchronous, and the source may
+// be reused by the caller immediately.  A slot is recycled only after its previous copy has completed.
+static int upload_small(gpx_handle* h, hipStream_t s, double* dst, const double* src, int64_t count) {
+  if (h->up_slot < count) {
+    GPX_HIP_CHECK(h, hipDeviceSynchronize());
+    if (h->h_up) (void)hipHostFree(h->h_up);
+    h->h_up = nullptr;
+    const int64_t slot = std::max<int64_t>(count, 64);
+    GPX_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_up), (size_t)(8 * slot) * sizeof(double), hipHostMallocDefault));
+    h->up_slot = slot;
+    for (auto& u : h->up_used) u = false;
+  }
+  const int i = h->up_next;
+  h->up_next = (i + 1) % 8;
+  if (!h->up_ev[i]) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->up_ev[i], hipEventDisableTiming));
+  if (h->up_used[i]) GPX_HIP_CHECK(h, hipEventSynchronize(h->up_ev[i]));
+  double* stage = h->h_up + (int64_t)i * h->up_slot;
+  memcpy(stage, src, (size_t)count * sizeof(double));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(dst, stage, (size_t)count * sizeof(double), hipMemcpyHostToDevice, s));
+  GPX_HIP_CHECK(h, hipEventRecord(h->up_ev[i], s));
+  h->up_used[i] = true;
+  return GPX_OK;
+}
+
 extern "C" int gpx_abi_version(void) { return GPX_ABI_VERSION; }
 
 // Three streams.  s_main carries the critical path (diagonal block, panel solve, near look-ahead) at
@@ -119,10 +179,13 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   gpx_handle* h = new gpx_handle();
   h->device = device_id;
   if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipGetDeviceProperties(&h->prop, device_id)) != hipSuccess ||
-      (e = create_streams(h)) != hipSuccess ||
-      (e = hipMalloc(reinterpret_cast<void**>(&h->d_scal), 8 * sizeof(double))) != hipSuccess ||
-      (e = hipMalloc(reinterpret_cast<void**>(&h->d_info), 4 * sizeof(int))) != hipSuccess) {
+      (e = create_streams(h)) != hipSuccess) {
     g_create_error = std::string("gpx_create: ") + hipGetErrorString(e);
+    delete h;
+    return GPX_ERR_HIP;
+  }
+  if (ensure_out(h, 2) != GPX_OK) {
+    g_create_error = std::string("gpx_create: ") + h->err;
     delete h;
     return GPX_ERR_HIP;
   }
@@ -149,10 +212,12 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   (void)hipDeviceSynchronize();
   gpx_dist_free(h);
   void* bufs[] = {h->d_x, h->d_xnew, h->d_r, h->d_mnew, h->d_hyp, h->d_noise, h->d_A, h->d_L, h->d_W,
-                  h->d_S, h->d_cov, h->d_z, h->d_scal, h->d_info, h->d_mean, h->d_g1, h->d_g2,
+                  h->d_S, h->d_cov, h->d_z, h->d_out, h->d_g1, h->d_g2,
                   h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2, h->d_kinv, h->d_gpart, h->d_mini};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
+  if (h->h_up) (void)hipHostFree(h->h_up);
+  for (auto e : h->up_ev) if (e) (void)hipEventDestroy(e);
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
@@ -250,7 +315,7 @@ static int upload_params(gpx_handle* h, hipStream_t s, const gpx_kernel_params* 
   hyp[2 * d + 2] = p->k_jitter;
   hyp[2 * d + 3] = kernel_diag_value(p->kind, p->k_scale) + (new_noise + p->k_jitter);
   GPX_RET(ensure(h, &h->d_hyp, &h->hyp_cap, 2 * (int64_t)d + 4));
-  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_hyp, hyp.data(), hyp.size() * sizeof(double), hipMemcpyHostToDevice, s));
+  GPX_RET(upload_small(h, s, h->d_hyp, hyp.data(), (int64_t)hyp.size()));
   if (p->n_noise > 1) {
     GPX_RET(ensure(h, &h->d_noise, &h->noise_cap, n));
     GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_noise, p->k_noise, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
@@ -689,7 +754,7 @@ static int factor_prepare(gpx_handle* h, int64_t m_rows, bool with_r) {
   GPX_RET(ensure(h, &h->d_L, &h->l_cap, rows * ld));
   GPX_RET(ensure(h, &h->d_W, &h->w_cap, npad * nb));
   GPX_RET(ensure(h, &h->d_z, &h->z_cap, npad));
-  GPX_RET(ensure(h, &h->d_mean, &h->out_cap, 2 * std::max<int64_t>(m_rows, 1)));
+  GPX_RET(ensure_out(h, 2 * std::max<int64_t>(m_rows, 1)));
   GPX_RET(ensure_events(h, (size_t)(npad / nb)));
   h->have_factor = false; h->have_z = false;
   h->npad = npad; h->epad = epad; h->ld = ld;
@@ -769,8 +834,9 @@ static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_ro
 }
 
 static int read_info(gpx_handle* h, int* info) {
-  GPX_HIP_CHECK(h, hipMemcpyAsync(info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, h->s_main));
-  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+  const double* blk;
+  GPX_RET(fetch_block(h, 0, &blk));
+  *info = reinterpret_cast<const int*>(blk + 8)[0];
   return GPX_OK;
 }
 
@@ -889,7 +955,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   GPX_RET(ensure(h, &h->d_r, &h->r_cap, n));
   GPX_RET(ensure(h, &h->d_vec, &h->vec_cap, 2 * npad));
   GPX_RET(ensure(h, &h->d_kinv, &h->kinv_cap, n64 * npad));
-  GPX_RET(ensure(h, &h->d_mean, &h->out_cap, 2));
+  GPX_RET(ensure_out(h, 2));
   GPX_RET(ensure_events(h, (size_t)(npad / nb)));
   h->npad = npad; h->epad = epad; h->ld = ld;
 
@@ -1028,7 +1094,7 @@ extern "C" int gpx_posterior(gpx_handle* h, const double* m_new, double new_nois
   g.lower_only = 0; g.diag_rule = 0; g.noise = nullptr; g.noise_scalar = 0.0; g.jitter = 0.0;
   GPX_RET(launch_gram(h, s, g));  // k_cross = f(x_new, x, apply_noise=False)  gpax/gp.py:282
   GPX_RET(solve_rows(h, S, X, mpad));
-  GPX_RET(ensure(h, &h->d_mean, &h->out_cap, 2 * m));
+  GPX_RET(ensure_out(h, 2 * m));
   h->d_var = h->d_mean + m;
   const double* mnew_dev = nullptr;
   if (m_new) {
@@ -1041,8 +1107,6 @@ extern "C" int gpx_posterior(gpx_handle* h, const double* m_new, double new_nois
   e.prior_diag = kernel_diag_value(q.kind, q.k_scale) + (new_noise + q.k_jitter);  // diagonal of k_new, gp.py:287
   e.scal = h->d_scal + 2; e.mean = h->d_mean; e.var = h->d_var;
   GPX_RET(launch_epilogue(h, s, e));
-  if (mean_out) GPX_HIP_CHECK(h, hipMemcpyAsync(mean_out, h->d_mean, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (var_out) GPX_HIP_CHECK(h, hipMemcpyAsync(var_out, h->d_var, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
   if (cov_out) {
     // cov = k_new - V^T V  (gpax/gp.py:298-299 with A = K^-1 k_cross^T = L^-T V)
     GPX_RET(ensure(h, &h->d_cov, &h->cov_cap, mpad * mpad));
@@ -1058,9 +1122,11 @@ extern "C" int gpx_posterior(gpx_handle* h, const double* m_new, double new_nois
     GPX_HIP_CHECK(h, hipMemcpy2DAsync(cov_out, (size_t)m * sizeof(double), h->d_cov, (size_t)mpad * sizeof(double),
                                       (size_t)m * sizeof(double), (size_t)m, hipMemcpyDeviceToHost, s));
   }
-  int info = 0;
-  GPX_RET(read_info(h, &info));
-  return info;
+  const double* blk;   // [scal | info | mean(m) | var(m)] in one copy
+  GPX_RET(fetch_block(h, 2 * m, &blk));
+  if (mean_out) memcpy(mean_out, blk + GPX_OUT_HEAD, (size_t)m * sizeof(double));
+  if (var_out) memcpy(var_out, blk + GPX_OUT_HEAD + m, (size_t)m * sizeof(double));
+  return reinterpret_cast<const int*>(blk + 8)[0];
 }
 
 extern "C" int gpx_prior_cov(gpx_handle* h, const gpx_kernel_params* p, double new_noise, double* cov_out) {
@@ -1221,11 +1287,14 @@ extern "C" int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, 
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
   hipStream_t s = h->s_main;
   const int64_t m = h->m_in_factor;
-  double scal[2]; int info = 0;
-  GPX_HIP_CHECK(h, hipMemcpyAsync(scal, h->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (mean_out && m > 0) GPX_HIP_CHECK(h, hipMemcpyAsync(mean_out, h->d_mean, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (var_out && m > 0) GPX_HIP_CHECK(h, hipMemcpyAsync(var_out, h->d_var, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPX_RET(read_info(h, &info));
+  (void)s;
+  // one copy: [scal | info | mean(m) | var(m)] (d_var = d_mean + max(m, 1), set by gpx_fit_predict_async)
+  const double* blk;
+  GPX_RET(fetch_block(h, m > 0 ? 2 * m : 0, &blk));
+  const double scal[2] = {blk[0], blk[1]};
+  const int info = reinterpret_cast<const int*>(blk + 8)[0];
+  if (mean_out && m > 0) memcpy(mean_out, blk + GPX_OUT_HEAD, (size_t)m * sizeof(double));
+  if (var_out && m > 0) memcpy(var_out, blk + GPX_OUT_HEAD + m, (size_t)m * sizeof(double));
   if (logp) *logp = -0.5 * scal[1] - scal[0] - 0.5 * (double)h->n * log(2.0 * M_PI);
   return info;
 }

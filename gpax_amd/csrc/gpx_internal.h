@@ -197,6 +197,11 @@ struct gpx_handle {
   int* d_info = nullptr;
   double* d_mean = nullptr; double* d_var = nullptr; int64_t out_cap = 0;  // d_var aliases d_mean + m
   double* h_pinned = nullptr; int64_t pinned_cap = 0;  // pinned staging for small results
+  // All small results live in ONE device block so that one copy brings them to the host:
+  //   d_out = [ scal[8] | info (4 ints) | mean[m] | var[m] ];  d_scal / d_info / d_mean / d_var point into it.
+  double* d_out = nullptr;
+  // pinned ring for hyper-parameter uploads (a pageable hipMemcpyAsync costs ~28 us of host time on this stack)
+  double* h_up = nullptr; int64_t up_slot = 0; int up_next = 0; hipEvent_t up_ev[8] = {}; bool up_used[8] = {};
 
   // captured hipGraphs of the fused fit+predict step, keyed by shape + buffer addresses
   std::map<std::string, hipGraphExec_t> graphs;

@@ -1,0 +1,28 @@
+// Standalone timing of the bulk-update GEMM (lower trapezoid, C -= A B^T) at a given shape: ./gemm_shape M N K
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../gpax_amd/csrc/gemm.hip"
+void gpx_set_error(gpx_handle*, const std::string& m) { printf("error: %s\n", m.c_str()); }
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv) {
+  const int64_t M = atoll(argv[1]), N = atoll(argv[2]);
+  const int64_t ld = N + 1024;
+  double *A, *L; CK(hipMalloc(&A, M * ld * 8)); CK(hipMalloc(&L, M * ld * 8));
+  CK(hipMemset(A, 0, M * ld * 8)); CK(hipMemset(L, 0, M * ld * 8));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int a = 3; a < argc; ++a) {
+    const int64_t K = atoll(argv[a]);
+    GemmLaunch t;
+    t.A = L; t.lda = ld; t.B = L; t.ldb = ld; t.C = A; t.ldc = ld;
+    t.M = M; t.N = N; t.K = K; t.alpha = -1.0; t.beta = 1.0; t.lower = 1; t.row_off = 0; t.col_off = 0; t.b_lower_tri = 0;
+    t.small_tile = 0; t.variant = 0;
+    const double entries = (double)N * (N + 1) / 2.0 + (double)(M - N) * N;
+    for (int w = 0; w < 2; ++w) launch_gemm_nt(nullptr, 0, t);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0)); for (int r = 0; r < 5; ++r) launch_gemm_nt(nullptr, 0, t); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
+    printf("M=%lld N=%lld K=%lld: %.1f us  %.1f TFLOP/s\n", (long long)M, (long long)N, (long long)K, ms * 1e3, 2.0 * entries * K / ms * 1e-9);
+  }
+  return 0;
+}
