@@ -13,7 +13,48 @@
 
 static std::string g_create_error;
 
+static std::mutex g_err_mutex;
+
+void HostWorker::start(int device) {
+  if (started) return;
+  started = true;
+  th = std::thread([this, device]() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      int spins = 0;
+      while (state.load(std::memory_order_acquire) == 0) {   // poll ~0.3 ms for the next job, then sleep
+        if (++spins > 20000) {
+          std::unique_lock<std::mutex> lk(m);
+          cv.wait(lk, [this] { return state.load(std::memory_order_acquire) != 0; });
+          break;
+        }
+      }
+      if (state.load(std::memory_order_acquire) == 3) return;
+      state.store(2, std::memory_order_release);
+      job();
+      state.store(0, std::memory_order_release);
+    }
+  });
+}
+void HostWorker::post(std::function<void()> f) {
+  job = std::move(f);
+  { std::lock_guard<std::mutex> lk(m); state.store(1, std::memory_order_release); }
+  cv.notify_one();
+}
+void HostWorker::wait() {
+  while (state.load(std::memory_order_acquire) != 0) { }
+}
+void HostWorker::stop() {
+  if (!started) return;
+  wait();
+  { std::lock_guard<std::mutex> lk(m); state.store(3, std::memory_order_release); }
+  cv.notify_one();
+  th.join();
+  started = false;
+}
+
 void gpx_set_error(gpx_handle* h, const std::string& msg) {
+  std::lock_guard<std::mutex> lk(g_err_mutex);
   if (h) h->err = msg; else g_create_error = msg;
 }
 
@@ -41,8 +82,16 @@ static hipEvent_t prof_event(gpx_handle* h) {
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 
+// mode 1: every launch is bracketed; mode 2 (coarse): only the whole step, the gram build and the epilogue --
+// three event pairs per step, so the brackets do not stretch what they measure
+static bool prof_stage_on(const gpx_handle* h, int stage) {
+  return h->prof_mode == 1 || (h->prof_mode == 2 && (stage == GPX_STAGE_FACTOR_TOTAL || stage == GPX_STAGE_GRAM || stage == GPX_STAGE_EPILOGUE));
+}
+
 void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double bytes) {
   if (!h->prof_mode) return;
+  h->prof_open = prof_stage_on(h, stage);
+  if (!h->prof_open) return;
   gpx_handle::PendingEv p;
   p.stage = stage; p.a = prof_event(h); p.b = prof_event(h);
   (void)hipEventRecord(p.a, s);
@@ -53,7 +102,7 @@ void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double by
 }
 
 void prof_end(gpx_handle* h, hipStream_t s) {
-  if (!h->prof_mode) return;
+  if (!h->prof_mode || !h->prof_open) return;
   (void)hipEventRecord(h->pending.back().b, s);
 }
 
@@ -135,6 +184,27 @@ static int upload_small(gpx_handle* h, hipStream_t s, double* dst, const double*
   return GPX_OK;
 }
 
+#ifdef GPX_TIMELINE
+void tl_set_gemm(unsigned long long* p);
+void tl_set_potrf(unsigned long long* p);
+static unsigned long long* g_tl_dev = nullptr;
+extern "C" int gpx_timeline_start(void) {
+  if (!g_tl_dev && hipMalloc(reinterpret_cast<void**>(&g_tl_dev), (4 + 4 * 16000) * 8) != hipSuccess) return -1;
+  (void)hipMemset(g_tl_dev, 0, (4 + 4 * 16000) * 8);
+  tl_set_gemm(g_tl_dev); tl_set_potrf(g_tl_dev);
+  return 0;
+}
+extern "C" long long gpx_timeline_read(unsigned long long* out, long long max_records) {
+  unsigned long long n = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpy(&n, g_tl_dev, 8, hipMemcpyDeviceToHost);
+  if (n > 16000) n = 16000;
+  if ((long long)n > max_records) n = (unsigned long long)max_records;
+  (void)hipMemcpy(out, g_tl_dev + 4, n * 32, hipMemcpyDeviceToHost);
+  return (long long)n;
+}
+#endif
+
 extern "C" int gpx_abi_version(void) { return GPX_ABI_VERSION; }
 
 // Three streams.  s_main carries the critical path (diagonal block, panel solve, near look-ahead) at
@@ -202,6 +272,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_DEPTH"))) h->depth = std::min(std::max(atoi(env), 1), 3);
   if ((env = getenv("GPX_PAIR_MIN"))) h->pair_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
+  if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   *out = h;
   return GPX_OK;
 }
@@ -209,6 +280,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
 extern "C" int gpx_destroy(gpx_handle* h) {
   if (!h) return GPX_OK;
   (void)hipSetDevice(h->device);
+  h->worker.stop();
   (void)hipDeviceSynchronize();
   gpx_dist_free(h);
   void* bufs[] = {h->d_x, h->d_xnew, h->d_r, h->d_mnew, h->d_hyp, h->d_noise, h->d_A, h->d_L, h->d_W,
@@ -221,6 +293,8 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_gram) (void)hipEventDestroy(h->ev_gram);
   for (auto e : h->ev_far) (void)hipEventDestroy(e);
   for (auto e : h->ev_w) (void)hipEventDestroy(e);
   for (auto e : h->ev_panel) (void)hipEventDestroy(e);
@@ -262,6 +336,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "depth")) { h->depth = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 3); return GPX_OK; }
   if (!strcmp(name, "pair_min")) { h->pair_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
+  if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -274,6 +349,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "depth")) { *value = h->depth; return GPX_OK; }
   if (!strcmp(name, "pair_min")) { *value = h->pair_min; return GPX_OK; }
   if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
+  if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -444,6 +520,8 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
   const unsigned fl = sync_event_flags();
   if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, fl));
   if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
+  if (!h->ev_fork) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_fork, fl));
+  if (!h->ev_gram) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_gram, fl));
   while (h->ev_far.size() < nblk) {
     hipEvent_t a, b;
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, fl));
@@ -586,11 +664,9 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld, nblk = npad / nb;
   hipStream_t P = h->s_main, Q = h->s_far, T = h->s_trail;
   double* A = h->d_A; double* L = h->d_L; double* S = h->d_mini;
-  std::vector<char> q_pending((size_t)nblk, 0), t_pending((size_t)nblk, 0);
   auto rows_at = [&](int64_t k) -> int64_t {
     return tri_base >= 0 ? std::min<int64_t>(rows_total, tri_base + (k + 1) * nb) : rows_total;
   };
-  bool q_used = false, t_used = false;
   // Grouped bulk updates while the factorisation is bulk-bound: T applies the g most recent panels in ONE
   // K = g nb pass every g-th step, cutting the read-modify-write passes over the trailing matrix g-fold (the bulk
   // kernel spends about as long on a tile's C traffic as on 128 columns of MFMA work; N = 16384: 42.0 ms with
@@ -604,29 +680,74 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
-  q_used = t_used = true;
+
+  // Host-side hand-shake between the two enqueueing threads: an event may only be waited for after the call
+  // that records it has been ISSUED (a wait on a not-yet-recorded event is a no-op).
+  const bool threaded = h->host_threads >= 2 && !h->prof_mode && !h->in_capture && nblk >= 4;
+  std::unique_ptr<std::atomic<int>[]> w_rec(new std::atomic<int>[(size_t)nblk]), far_rec(new std::atomic<int>[(size_t)nblk]);
+  for (int64_t k = 0; k < nblk; ++k) { w_rec[(size_t)k].store(0); far_rec[(size_t)k].store(0); }
+  std::atomic<int> abort_flag{0};
+  auto await = [&](std::atomic<int>& f) -> bool {   // false: the other side failed
+    if (!threaded) return true;
+    while (f.load(std::memory_order_acquire) == 0)
+      if (abort_flag.load(std::memory_order_acquire)) return false;
+    return true;
+  };
+
+  // ---- the chain (stream P) at step k: potrf, then the diagonal band
+  auto chain = [&](int64_t k) -> int {
+    const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
+    prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
+    GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
+                              h->d_info, (int)c0));
+    prof_end(h, P);
+    if (rows - r0 <= 0) return GPX_OK;
+    // recorded HERE, not after the two band kernels: measured 1.91 -> 2.12 ms per N = 4096 step when the panel
+    // stream learns of W_k 12 us later
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
+    w_rec[(size_t)k].store(1, std::memory_order_release);
+    if (k + 1 >= nblk) return GPX_OK;
+    if (k >= 1) {   // columns k, k+1 were brought up to date by Q at step k-1
+      if (!await(far_rec[(size_t)(k - 1)])) return GPX_ERR_HIP;
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
+    }
+    GemmLaunch g;
+    g.A = A + r0 * ld + c0; g.lda = ld;
+    g.B = h->d_W + k * nb * nb; g.ldb = nb;
+    g.C = S; g.ldc = nb;
+    g.M = nb; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+    g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+    prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
+    GPX_RET(launch_gemm_nt(h, P, g));
+    prof_end(h, P);
+    GemmLaunch u;
+    u.A = S; u.lda = nb; u.B = S; u.ldb = nb;
+    u.C = A + r0 * ld + r0; u.ldc = ld;
+    u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
+    u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
+    prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
+    GPX_RET(launch_gemm_nt(h, P, u));
+    prof_end(h, P);
+    return GPX_OK;
+  };
+
+  // ---- the side streams at step k: Q (whole panel, columns k+1 and k+2), T (bulk)
   const int64_t pair_min = h->pair_min, quad_min = h->quad_min;
   int64_t last_t = -1;        // last step at which T acted (panels <= last_t are in every column >= last_t+3)
   int64_t group_end = -1;     // the step at which T acts next
   int64_t q_waited_t = -1;    // the T step Q has already waited for
-  for (int64_t k = 0; k < nblk; ++k) {
+  std::vector<char> t_pending((size_t)nblk, 0);
+  auto side = [&](int64_t k) -> int {
     if (k > group_end) {
       const int64_t left = nblk - k;
       const int64_t g = (quad_min > 0 && left > quad_min) ? 4 : ((pair_min > 0 && left > pair_min) ? 2 : 1);
       group_end = k + g - 1;
     }
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
-    prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
-    GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
-                              h->d_info, (int)c0));
-    prof_end(h, P);
     const int64_t mrows = rows - r0;
-    if (mrows <= 0) continue;
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
-
-    // ---- Q: the whole panel
+    if (mrows <= 0) return GPX_OK;
+    if (!await(w_rec[(size_t)k])) return GPX_ERR_HIP;
     GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
-    q_used = true;
     {
       GemmLaunch g;
       g.A = A + r0 * ld + c0; g.lda = ld;
@@ -638,36 +759,20 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       GPX_RET(launch_gemm_nt(h, Q, g));
       prof_end(h, Q);
     }
-    if (k + 1 >= nblk) continue;   // border rows only: nothing left to update
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
+    if (k + 1 >= nblk) return GPX_OK;   // border rows only: nothing left to update
+    // its own record for T: the bulk update must not wait for the column kernels below (with one shared record
+    // after them the N = 4096 step went from 1.90 to 2.17 ms: the early, bulk-bound phase starts every update late)
+    if (k == group_end && nblk - (k + 3) > 0) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
 
-    // ---- P: the diagonal band
-    if (k >= 1 && q_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
-    {
-      GemmLaunch g;
-      g.A = A + r0 * ld + c0; g.lda = ld;
-      g.B = h->d_W + k * nb * nb; g.ldb = nb;
-      g.C = S; g.ldc = nb;
-      g.M = nb; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
-      g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-      prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
-      GPX_RET(launch_gemm_nt(h, P, g));
-      prof_end(h, P);
-      GemmLaunch u;
-      u.A = S; u.lda = nb; u.B = S; u.ldb = nb;
-      u.C = A + r0 * ld + r0; u.ldc = ld;
-      u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
-      u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
-      prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
-      GPX_RET(launch_gemm_nt(h, P, u));
-      prof_end(h, P);
-    }
-
-    // ---- Q: columns k+1 (below its diagonal block; panel k) and k+2 (every panel since T's last step),
-    // rows from block row k+2 down
+    // columns k+1 (below its diagonal block; panel k) and k+2 (every panel since T's last step), rows from
+    // block row k+2 down
     const int64_t rr = (k + 2) * nb, mr = rows - rr;
     const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
     if (mr > 0) {
+      if (h->gram_pending && k >= 1) {   // columns >= 3 were built on T (split gram build)
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_gram, 0));
+        h->gram_pending = false;
+      }
       if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {   // column k+2 was last written there
         GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
         q_waited_t = last_t;
@@ -696,14 +801,13 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       }
     }
     GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
-    q_pending[(size_t)k] = 1;
+    far_rec[(size_t)k].store(1, std::memory_order_release);
 
-    // ---- T: bulk, columns >= k+3, panels last_t+1 .. k in one pass
+    // T: bulk, columns >= k+3, panels last_t+1 .. k in one pass
     const int64_t nbulk = nblk - (k + 3);
     if (k == group_end) {
       if (nbulk > 0) {
         GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
-        t_used = true;
         const int64_t kfirst = last_t + 1, npan = k - last_t;
         const int64_t cf = k + 3, br = cf * nb, bm = rows - br, nc = nbulk * nb;
         GemmLaunch t;
@@ -721,15 +825,32 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       }
       last_t = k;
     }
+    return GPX_OK;
+  };
+
+  int rc = GPX_OK;
+  if (threaded) {
+    int side_rc = GPX_OK;
+    h->worker.start(h->device);
+    h->worker.post([&]() {
+      for (int64_t k = 0; k < nblk && side_rc == GPX_OK; ++k) side_rc = side(k);
+      if (side_rc != GPX_OK) abort_flag.store(1, std::memory_order_release);
+    });
+    for (int64_t k = 0; k < nblk && rc == GPX_OK; ++k) rc = chain(k);
+    if (rc != GPX_OK) abort_flag.store(1, std::memory_order_release);
+    h->worker.wait();
+    if (rc == GPX_OK) rc = side_rc;
+  } else {
+    for (int64_t k = 0; k < nblk && rc == GPX_OK; ++k) {
+      rc = chain(k);
+      if (rc == GPX_OK) rc = side(k);
+    }
   }
-  if (t_used) {
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
-  }
-  if (q_used) {
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join2, 0));
-  }
+  GPX_RET(rc);
+  GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
+  GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
+  GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));
+  GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join2, 0));
   return GPX_OK;
 }
 
@@ -777,38 +898,74 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   g.x1 = h->d_x; g.x2 = h->d_x; g.n1 = n; g.n2 = n; g.out = h->d_A; g.ld = ld;
   g.lower_only = fp.want_k ? 0 : 1; g.diag_rule = fp.apply_noise ? 1 : 0;
   g.noise = fp.noise_dev; g.noise_scalar = 0.0; g.jitter = 0.0;
-  {
-    const double T = (double)((n + 63) / 64);
-    const double entries = fp.want_k ? (double)n * n : T * (T + 1) / 2.0 * 4096.0;
-    prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(fp.kind, d) * entries, 8.0 * entries + 16.0 * n * d);
-    GPX_RET(launch_gram(h, s, g));
-    prof_end(h, s);
-  }
-  if (K_out) {
-    GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
-                                      (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
-  }
-  GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
-  if (m_rows > 0) {
+  auto gram_cost = [&](int64_t c0, int64_t c1, double* fl, double* by) {   // lower tiles of the column slice [c0, c1)
+    double entries = 0.0;
+    for (int64_t c = c0 / 64; c * 64 < c1; ++c) entries += (double)((n + 63) / 64 - c) * 4096.0;
+    if (fp.want_k) entries = (double)n * (double)(c1 - c0);
+    *fl = gram_flops_per_entry(fp.kind, d) * entries; *by = 8.0 * entries + 8.0 * (double)(n + c1 - c0) * d;
+  };
+  auto cross_gram = [&](hipStream_t st) -> int {
+    if (m_rows <= 0) return GPX_OK;
     GramLaunch c = g;
     c.x1 = h->d_xnew; c.n1 = m_rows; c.out = h->d_A + npad * ld; c.lower_only = 0; c.diag_rule = 0;
-    c.noise = nullptr;
-    prof_begin(h, s, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(fp.kind, d) * m_rows * n,
+    c.noise = nullptr; c.zero_info = nullptr; c.col0 = 0; c.x2 = h->d_x; c.n2 = n;
+    prof_begin(h, st, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(fp.kind, d) * m_rows * n,
                8.0 * m_rows * n + 8.0 * (m_rows + n) * d);
-    GPX_RET(launch_gram(h, s, c));
+    int rc = launch_gram(h, st, c);
+    prof_end(h, st);
+    return rc;
+  };
+  const int64_t csplit = 3 * h->nb;
+  static int split_env = -1;
+  if (split_env < 0) { const char* e = getenv("GPX_GRAM_SPLIT"); split_env = e ? atoi(e) : 1; }
+  const bool split = split_env != 0 && h->lookahead != 0 && h->depth >= 3 && !fp.want_k && n > csplit;
+  h->gram_pending = false;
+  double fl, by;
+  if (!split) {
+    g.zero_info = h->d_info;
+    gram_cost(0, n, &fl, &by);
+    prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
+    GPX_RET(launch_gram(h, s, g));
     prof_end(h, s);
+    if (K_out) {
+      GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
+                                        (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
+    }
+    GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
+    GPX_RET(cross_gram(s));
+    // the r row and the unused (zero) border rows in one launch
+    GPX_RET(launch_border_rows(h, s, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
+  } else {
+    // Split build for the split-panel schedule: the chain stream builds only the three block columns the first
+    // steps need and starts factorising; the rest of K is built on the bulk stream (in front of its first
+    // update), k_cross and the border rows on the panel stream (in front of its first panel).  ~40 us of
+    // serial prologue per N = 4096 step leave the critical path.
+    hipStream_t Q = h->s_far, T = h->s_trail;
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_fork, s));          // hyper-parameters are uploaded, the last step has joined
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_fork, 0));
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_fork, 0));
+    GramLaunch g1 = g;
+    g1.n2 = csplit; g1.col0 = 0; g1.zero_info = h->d_info;
+    gram_cost(0, csplit, &fl, &by);
+    prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
+    GPX_RET(launch_gram(h, s, g1));
+    prof_end(h, s);
+    GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
+    GramLaunch g2 = g;
+    g2.x2 = h->d_x + csplit * d; g2.n2 = n - csplit; g2.col0 = csplit; g2.out = h->d_A + csplit;
+    gram_cost(csplit, n, &fl, &by);
+    prof_begin(h, T, GPX_STAGE_GRAM, fl, by);
+    GPX_RET(launch_gram(h, T, g2));
+    prof_end(h, T);
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_gram, T));
+    h->gram_pending = true;
+    GPX_RET(cross_gram(Q));
+    GPX_RET(launch_border_rows(h, Q, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
   }
-  if (fp.with_r) GPX_RET(launch_set_row(h, s, h->d_A + (npad + m_rows) * ld, h->d_r, n, npad));
-  GPX_RET(launch_fill_rect(h, s, h->d_A, ld, npad + E, rows, 0, n, 0.0));  // unused border rows
-  GPX_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
 
   GPX_RET(factor_loop(h, rows));
 
-  if (fp.with_r) {  // keep z = L^-1 r for later posterior calls against the cached factor
-    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_z, h->d_L + (npad + m_rows) * ld, (size_t)npad * sizeof(double),
-                                    hipMemcpyDeviceToDevice, s));
-  }
-  return GPX_OK;
+  return GPX_OK;   // z = L^-1 r (row npad + m_rows of d_L) is copied to d_z by the fused epilogue of the caller
 }
 
 static void factor_commit(gpx_handle* h, const gpx_kernel_params* p, int64_t m_rows, bool with_r) {
@@ -991,10 +1148,10 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
 
   const double* zrow = h->d_L + npad * ld;
   const double* U = h->d_L + (npad + RZ) * ld;
-  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_z, zrow, (size_t)npad * sizeof(double), hipMemcpyDeviceToDevice, s));
   EpilogueLaunch e;
-  e.L = h->d_L; e.ld = ld; e.n = n; e.z = h->d_z; e.vt = nullptr; e.vt_ld = 0; e.m = 0; e.m_new = nullptr;
+  e.L = h->d_L; e.ld = ld; e.n = n; e.z = zrow; e.vt = nullptr; e.vt_ld = 0; e.m = 0; e.m_new = nullptr;
   e.prior_diag = 0.0; e.scal = h->d_scal; e.mean = nullptr; e.var = nullptr;
+  e.z_copy = h->d_z; e.npad = npad;
   GPX_RET(launch_epilogue(h, s, e));
 
   // ---- alpha = L^-T z = U z
@@ -1211,6 +1368,7 @@ static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
   e.m_new = h->have_mnew ? h->d_mnew : nullptr;
   e.prior_diag = 0.0; e.dev_prior_diag = h->d_hyp + 2 * h->d + 3;
   e.scal = h->d_scal; e.mean = h->d_mean; e.var = h->d_var;
+  e.z_copy = h->d_z; e.npad = h->npad;   // keep z for later posterior calls against the cached factor
   prof_begin(h, s, GPX_STAGE_EPILOGUE, 4.0 * (m + 1.0) * h->n, 8.0 * (m + 2.0) * h->n);
   GPX_RET(launch_epilogue(h, s, e));
   prof_end(h, s);
@@ -1251,7 +1409,9 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
       const bool trace = getenv("GPX_TRACE") != nullptr;
       if (trace) fprintf(stderr, "[gpx] begin capture\n");
       GPX_HIP_CHECK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      h->in_capture = true;
       int rc = fit_predict_enqueue(h, fp);
+      h->in_capture = false;
       if (trace) fprintf(stderr, "[gpx] enqueue rc=%d, end capture\n", rc);
       hipError_t ce = hipStreamEndCapture(s, &graph);
       if (trace) fprintf(stderr, "[gpx] end capture: %s\n", hipGetErrorString(ce));

@@ -56,6 +56,25 @@ __device__ __forceinline__ bool tile_from_block(const struct GemmArgs& g, int64_
 #define GEMM_BK 32
 #define GEMM_LDT (GEMM_BK + 4)
 
+// Diagnostic build only (make TIMELINE=1 -> libgpx_hip_tl.so, tools/timeline2.py): the first thread of every
+// kernel logs (kind, s_memrealtime, M, N) into a device buffer -- an unperturbed timeline of kernel STARTS.
+#ifdef GPX_TIMELINE
+__device__ unsigned long long* g_tl_gemm;
+void tl_set_gemm(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_gemm), &p, sizeof(p)); }
+#define GEMM_TL(kind, a, b)                                                                                  \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_tl_gemm) {                               \
+      const unsigned long long slot = atomicAdd(g_tl_gemm, 1ull);                                            \
+      if (slot < 16000) {                                                                                    \
+        unsigned long long* r = g_tl_gemm + 4 + 4 * slot;                                                    \
+        r[0] = (kind); r[1] = __builtin_amdgcn_s_memrealtime(); r[2] = (unsigned long long)(a); r[3] = (unsigned long long)(b); \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
+#else
+#define GEMM_TL(kind, a, b) do { } while (0)
+#endif
+
 // Diagnostic build only (tools/gemm_bench): s_memtime stamps of one workgroup's phases.
 #ifdef GPX_GEMM_STAMPS
 __device__ unsigned long long* g_gemm_stamps;
@@ -103,6 +122,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  GEMM_TL(4, g.M, g.N * 1000000 + g.K);
   int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
   if (g.map_S > 0) {
     int64_t ti, tj;
@@ -212,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + wm * (BM / 2) + i * 16 + fk + 4 * r;
+        // (non-temporal and agent-scope write-through stores were A/B-tested here: no effect on the step time)
         g.C[row * g.ldc + col] = fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]);
       }
     }
@@ -367,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+  GEMM_TL(3, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));
   if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
   const double* Ag = g.A + m0 * g.lda;
   const double* Bg = g.B + n0 * g.ldb;

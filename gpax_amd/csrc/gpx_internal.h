@@ -4,8 +4,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <set>
+#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -55,6 +60,8 @@ struct GramLaunch {
   const int64_t* row_gid = nullptr;  // device: global row id per x1 row (diagonal rule / noise index); NULL: row itself
   double noise_scalar;  // used when noise == NULL
   double jitter;
+  int64_t col0 = 0;     // x2 / out are the column slice starting at this global column (lower test, diagonal rule)
+  int* zero_info = nullptr;  // device int cleared by the launch
 };
 int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& g);
 
@@ -90,6 +97,9 @@ int launch_fill_identity_pad(gpx_handle* h, hipStream_t s, double* A, int64_t ld
                              int64_t npad, int64_t rows_total);
 int launch_set_row(gpx_handle* h, hipStream_t s, double* dst, const double* src, int64_t n,
                    int64_t npad);
+// one launch: row `r_row` of A <- r (n entries, zero padded to npad; skipped when r_row < 0), rows [z0, z1) <- 0, *info <- 0
+int launch_border_rows(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t npad, int64_t n, int64_t r_row,
+                       const double* r, int64_t z0, int64_t z1, int* info);
 
 // epilogue reductions
 struct EpilogueLaunch {
@@ -103,6 +113,7 @@ struct EpilogueLaunch {
   const double* dev_prior_diag = nullptr;  // device copy (graph replays); overrides prior_diag
   double* scal;                  // device: [0]=logdet [1]=quad
   double* mean; double* var;     // device (m)
+  double* z_copy = nullptr; int64_t npad = 0;   // also copy z[0:npad) here (the handle's z for later posterior calls)
 };
 int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
 
@@ -134,6 +145,24 @@ struct DistState {
   void* comm = nullptr;                                  // ncclComm_t
 };
 void gpx_dist_free(gpx_handle* h);
+
+// A second host thread for enqueueing.  One N = 4096 factorisation is ~350 launch / event calls (~4 us of host
+// time each): issued from one thread the host needs 1.45 ms for a step the GPU finishes in 1.9, i.e. the GPU
+// runs right behind the launcher.  The split-panel schedule therefore issues the chain stream's calls from the
+// caller's thread and the panel / update streams' calls from this worker, ordered by host-side flags wherever
+// one side waits on an event the other records.  The worker spins briefly for the next job before it sleeps.
+struct HostWorker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  std::atomic<int> state{0};   // 0 idle, 1 job posted, 2 running, 3 exit
+  bool started = false;
+  void start(int device);
+  void post(std::function<void()> f);
+  void wait();
+  void stop();
+};
 
 // ------------------------------------------------------------------------ the handle
 struct StageProf {
@@ -205,18 +234,22 @@ struct gpx_handle {
 
   // captured hipGraphs of the fused fit+predict step, keyed by shape + buffer addresses
   std::map<std::string, hipGraphExec_t> graphs;
-  std::set<std::string> graph_warm;   // shapes that have run eagerly once (capture starts on the second call)
+  std::set<std::string> graph_warm;
+  bool in_capture = false;   // a stream capture is in progress: enqueue from the caller's thread only
+  int host_threads = 1;      // 2: the side streams are fed by the worker thread (split-panel schedule); 1: one thread
+  HostWorker worker;   // shapes that have run eagerly once (capture starts on the second call)
 
   // events for the two-stream lookahead
   std::vector<hipEvent_t> ev_panel, ev_trail;
   hipEvent_t ev_join = nullptr, ev_join2 = nullptr;
   std::vector<hipEvent_t> ev_far, ev_w;
+  hipEvent_t ev_fork = nullptr, ev_gram = nullptr; bool gram_pending = false;   // split gram build (depth 3)
   double* d_mini = nullptr; int64_t mini_cap = 0;   // nb x nb scratch of the split-panel schedule (L_{k+1,k} for the chain)
 
   DistState dist;
 
   // profiling
-  int prof_mode = 0;
+  int prof_mode = 0; bool prof_open = false;
   StageProf prof[GPX_N_STAGES];
   struct PendingEv { int stage; hipEvent_t a, b; };
   std::vector<PendingEv> pending;

@@ -34,6 +34,8 @@ struct GramArgs {
   int d;
   int lower_only, diag_rule;
   double k_scale, noise_scalar, jitter;
+  int64_t col0;      // global index of x2's first row / out's first column (column slices of one matrix)
+  int* zero_info;    // when set, workgroup (0,0) clears it (saves the factorisation a memset launch)
 };
 
 template <int KIND, bool VEC2>
@@ -46,7 +48,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 
   const int tid = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
-  if (g.lower_only && j0 > i0 + GT - 1) return;
+  if (g.zero_info && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *g.zero_info = 0;
+  if (g.lower_only && g.col0 + j0 > i0 + GT - 1) return;
 
   const int cj = tid & 31;   // column pair: cols 2cj, 2cj+1
   const int ri = tid >> 5;   // row group: rows 8ri .. 8ri+7
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
         k = k_scale * exp(-2.0 * r2);                       // kernels.py:165
       }
       const int64_t grow = g.row_gid ? g.row_gid[row] : row;
-      if (g.diag_rule && grow == col + c) {
+      if (g.diag_rule && grow == g.col0 + col + c) {
         const double nz = g.noise ? g.noise[grow] : noise_scalar;
         k += (nz + jitter);                                 // kernels.py:124-125
       }
@@ -149,6 +152,7 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   g.n1 = L.n1; g.n2 = L.n2; g.ld = L.ld; g.d = L.d;
   g.lower_only = L.lower_only; g.diag_rule = L.diag_rule;
   g.k_scale = L.k_scale; g.noise_scalar = L.noise_scalar; g.jitter = L.jitter;
+  g.col0 = L.col0; g.zero_info = L.zero_info;
   dim3 grid((unsigned)((L.n2 + GT - 1) / GT), (unsigned)((L.n1 + GT - 1) / GT));
   const bool vec2 = (L.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(L.out) & 15) == 0);
 #define GPX_GRAM_LAUNCH(KIND)                                                        \
@@ -206,6 +210,29 @@ int launch_set_row(gpx_handle* h, hipStream_t s, double* dst, const double* src,
   if (npad <= 0) return GPX_OK;
   hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, s, dst, src,
                      n, npad);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
+// row r_row <- r, rows [z0, z1) <- 0 (columns [0, n) each), *info <- 0: the per-step border bookkeeping in one launch
+__global__ void border_rows_kernel(double* A, int64_t ld, int64_t npad, int64_t n, int64_t r_row, const double* r,
+                                   int64_t z0, int64_t z1, int* info) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && info) *info = 0;
+  if (c >= n) return;   // columns [n, npad) of every row belong to launch_fill_identity_pad
+  if (blockIdx.y == 0) {
+    if (r_row >= 0) A[r_row * ld + c] = r ? r[c] : 0.0;
+    return;
+  }
+  const int64_t row = z0 + (int64_t)blockIdx.y - 1;
+  if (row < z1) A[row * ld + c] = 0.0;
+}
+
+int launch_border_rows(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t npad, int64_t n, int64_t r_row,
+                       const double* r, int64_t z0, int64_t z1, int* info) {
+  const int64_t nz = z1 > z0 ? z1 - z0 : 0;
+  hipLaunchKernelGGL(border_rows_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)(nz + 1)), dim3(256), 0, s, A, ld,
+                     npad, n, r_row, r, z0, z1, info);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

@@ -392,6 +392,23 @@ __device__ __forceinline__ void store_tile(const double* tiles, double* dst, int
 //   leaf(0) | for jb: phase A (sub-panel solve, all waves) | { wave 0: update tile (jb+1,jb+1),
 //   leaf(jb+1) }  ||  { other waves: the rest of the rank-16 update, then row jb of W }
 // so the in-block trailing update and the whole inversion hide behind the leaf chain.
+#ifdef GPX_TIMELINE
+__device__ unsigned long long* g_tl_potrf;
+void tl_set_potrf(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_potrf), &p, sizeof(p)); }
+#define POTRF_TL(kind, a)                                                                       \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && g_tl_potrf) {                                                       \
+      const unsigned long long slot = atomicAdd(g_tl_potrf, 1ull);                              \
+      if (slot < 16000) {                                                                       \
+        unsigned long long* r = g_tl_potrf + 4 + 4 * slot;                                      \
+        r[0] = (kind); r[1] = __builtin_amdgcn_s_memrealtime(); r[2] = (unsigned long long)(a); r[3] = 0; \
+      }                                                                                         \
+    }                                                                                           \
+  } while (0)
+#else
+#define POTRF_TL(kind, a) do { } while (0)
+#endif
+
 template <int NB, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* __restrict__ A,
                                                                  int64_t lda, double* __restrict__ L,
@@ -405,6 +422,7 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
+  POTRF_TL(1, col0);
   GPX_STAMP(0);
   for (int t = tid; t < LEAF_SHARE_DOUBLES; t += NWAVES * 64) sh[t] = 0.0;   // epochs start at 0
 
@@ -528,6 +546,7 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
     }
   }
   GPX_STAMP(3 + 2 * NT);
+  POTRF_TL(2, col0);
 }
 
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda, double* L,

@@ -31,17 +31,6 @@ __device__ __forceinline__ void block_sum2(double& a, double& b) {
   }
 }
 
-__global__ __launch_bounds__(1024) void lml_reduce_kernel(const double* L, int64_t ld, int64_t n,
-                                                         const double* z, double* scal) {
-  double s1 = 0.0, s2 = 0.0;
-  for (int64_t i = threadIdx.x; i < n; i += 1024) {
-    s1 += log(L[i * ld + i]);
-    if (z) { const double v = z[i]; s2 = fma(v, v, s2); }
-  }
-  block_sum2<1024>(s1, s2);
-  if (threadIdx.x == 0) { scal[0] = s1; scal[1] = s2; }
-}
-
 __global__ __launch_bounds__(256) void post_reduce_kernel(const double* vt, int64_t ld, int64_t n,
                                                          const double* z, const double* m_new,
                                                          double prior_diag, const double* dev_prior_diag,
@@ -61,14 +50,44 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const double* vt, int6
   }
 }
 
-int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
-  hipLaunchKernelGGL(lml_reduce_kernel, dim3(1), dim3(1024), 0, s, e.L, e.ld, e.n, e.z, e.scal);
-  GPX_HIP_CHECK(h, hipGetLastError());
-  if (e.m > 0 && e.z) {
-    hipLaunchKernelGGL(post_reduce_kernel, dim3((unsigned)e.m), dim3(256), 0, s, e.vt, e.vt_ld, e.n, e.z,
-                       e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var);
-    GPX_HIP_CHECK(h, hipGetLastError());
+// Fused epilogue: block 0 = the log-marginal pieces (and, on request, the copy of z into the handle's z
+// buffer for later posterior calls), blocks 1..m = one test row each.  One launch instead of a device copy and
+// two kernels at the tail of every fit+predict step.
+__global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t ld, int64_t n, const double* z,
+                                                      double* z_copy, int64_t npad, double* scal, const double* vt,
+                                                      int64_t vt_ld, const double* m_new, double prior_diag,
+                                                      const double* dev_prior_diag, double* mean, double* var) {
+  if (blockIdx.x == 0) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t i = threadIdx.x; i < npad; i += 256) {
+      const double v = z ? z[i] : 0.0;
+      if (z_copy) z_copy[i] = v;
+      if (i < n) { s1 += log(L[i * ld + i]); s2 = fma(v, v, s2); }
+    }
+    block_sum2<256>(s1, s2);
+    if (threadIdx.x == 0) { scal[0] = s1; scal[1] = s2; }
+    return;
   }
+  const int64_t row = blockIdx.x - 1;
+  const double* v = vt + row * vt_ld;
+  double dot = 0.0, ss = 0.0;
+  for (int64_t c = threadIdx.x; c < n; c += 256) {
+    const double x = v[c];
+    dot = fma(x, z[c], dot);
+    ss = fma(x, x, ss);
+  }
+  block_sum2<256>(dot, ss);
+  if (threadIdx.x == 0) {
+    mean[row] = (m_new ? m_new[row] : 0.0) + dot;
+    var[row] = (dev_prior_diag ? dev_prior_diag[0] : prior_diag) - ss;
+  }
+}
+
+int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
+  const int64_t rows = (e.m > 0 && e.z) ? e.m : 0;
+  hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(rows + 1)), dim3(256), 0, s, e.L, e.ld, e.n, e.z, e.z_copy,
+                     e.z_copy ? e.npad : e.n, e.scal, e.vt, e.vt_ld, e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var);
+  GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
 
