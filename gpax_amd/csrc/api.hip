@@ -917,7 +917,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   };
   const int64_t csplit = 3 * h->nb;
   static int split_env = -1;
-  if (split_env < 0) { const char* e = getenv("GPX_GRAM_SPLIT"); split_env = e ? atoi(e) : 1; }
+  if (split_env < 0) { const char* e = getenv("GPX_GRAM_SPLIT"); split_env = e ? atoi(e) : 0; }
   const bool split = split_env != 0 && h->lookahead != 0 && h->depth >= 3 && !fp.want_k && n > csplit;
   h->gram_pending = false;
   double fl, by;
@@ -936,10 +936,11 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     // the r row and the unused (zero) border rows in one launch
     GPX_RET(launch_border_rows(h, s, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
   } else {
-    // Split build for the split-panel schedule: the chain stream builds only the three block columns the first
-    // steps need and starts factorising; the rest of K is built on the bulk stream (in front of its first
-    // update), k_cross and the border rows on the panel stream (in front of its first panel).  ~40 us of
-    // serial prologue per N = 4096 step leave the critical path.
+    // Split build for the split-panel schedule (GPX_GRAM_SPLIT=1; off by default): the chain stream builds only
+    // the three block columns the first steps need and starts factorising; the rest of K is built on the bulk
+    // stream (in front of its first update), k_cross and the border rows on the panel stream.  Measured: no gain
+    // at N = 4096 (1.907 vs 1.905 ms) -- the first steps are bound by the bulk stream, which now also carries
+    // most of the gram build -- so the plain sequence stays the default.
     hipStream_t Q = h->s_far, T = h->s_trail;
     GPX_HIP_CHECK(h, hipEventRecord(h->ev_fork, s));          // hyper-parameters are uploaded, the last step has joined
     GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_fork, 0));

@@ -195,18 +195,29 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       }
   }
   for (int64_t k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+#if defined(GPX_ABLATE) && (GPX_ABLATE & 2)
+    if (k0 == kbeg)
+#endif
     store_tiles();
     GEMM_STAMP(1 + 3 * (int)(k0 / GEMM_BK));
     __syncthreads();
     GEMM_STAMP(2 + 3 * (int)(k0 / GEMM_BK));
+#if defined(GPX_ABLATE) && (GPX_ABLATE & 1)
+#else
     if (k0 + GEMM_BK < kend) load_tiles(k0 + GEMM_BK);  // in flight during the MFMAs below
+#endif
 #pragma unroll
     for (int s = 0; s < GEMM_BK / 8; ++s) {
       v2d a[TM], b[TN];
+#if defined(GPX_ABLATE) && (GPX_ABLATE & 8)
+      if (s == 0 && k0 == kbeg)
+#endif
+      {
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const v2d*>(Ap + i * 16 * GEMM_LDT + 8 * s);
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const v2d*>(Bp + j * 16 * GEMM_LDT + 8 * s);
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -219,7 +230,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
           acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
     }
     GEMM_STAMP(3 + 3 * (int)(k0 / GEMM_BK));
+#if defined(GPX_ABLATE) && (GPX_ABLATE & 4)
+#else
     __syncthreads();
+#endif
   }
   GEMM_STAMP(13);
 

@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
     GemmLaunch t;
     t.A = L; t.lda = ld; t.B = L; t.ldb = ld; t.C = A; t.ldc = ld;
     t.M = M; t.N = N; t.K = K; t.alpha = -1.0; t.beta = 1.0; t.lower = 1; t.row_off = 0; t.col_off = 0; t.b_lower_tri = 0;
-    t.small_tile = 0; t.variant = 0;
+    t.small_tile = 0; t.variant = getenv("VARIANT") ? atoi(getenv("VARIANT")) : 0;
     const double entries = (double)N * (N + 1) / 2.0 + (double)(M - N) * N;
     for (int w = 0; w < 2; ++w) launch_gemm_nt(nullptr, 0, t);
     CK(hipDeviceSynchronize());
