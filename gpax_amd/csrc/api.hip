@@ -694,17 +694,23 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     return true;
   };
 
+  // completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL stopEvent) except inside a
+  // stream capture and under per-launch profiling, where they are recorded behind the kernel as usual
+  const bool attach = !h->in_capture && !h->prof_mode;
+
   // ---- the chain (stream P) at step k: potrf, then the diagonal band
   auto chain = [&](int64_t k) -> int {
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
+    // ev_w[k] = completion of potrf_diag(k): attached to the kernel's own dispatch when possible (no barrier
+    // packet behind it), else recorded right after it -- NOT after the two band kernels (measured 1.91 -> 2.12 ms
+    // per N = 4096 step when the panel stream learns of W_k 12 us later)
+    const bool need_w = rows - r0 > 0;
     prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
     GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
-                              h->d_info, (int)c0));
+                              h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr));
     prof_end(h, P);
-    if (rows - r0 <= 0) return GPX_OK;
-    // recorded HERE, not after the two band kernels: measured 1.91 -> 2.12 ms per N = 4096 step when the panel
-    // stream learns of W_k 12 us later
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
+    if (!need_w) return GPX_OK;
+    if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
     w_rec[(size_t)k].store(1, std::memory_order_release);
     if (k + 1 >= nblk) return GPX_OK;
     if (k >= 1) {   // columns k, k+1 were brought up to date by Q at step k-1
@@ -755,19 +761,22 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       g.C = L + r0 * ld + c0; g.ldc = ld;
       g.M = mrows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
       g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+      // T gets its own event on the panel: the bulk update must not wait for the column kernels below (with one
+      // shared event after them the N = 4096 step went from 1.90 to 2.17 ms: every bulk update starts late)
+      const bool t_needs = k + 1 < nblk && k == group_end && nblk - (k + 3) > 0;
+      if (t_needs && attach) g.stop_event = h->ev_panel[(size_t)k];
       prof_begin(h, Q, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
       GPX_RET(launch_gemm_nt(h, Q, g));
       prof_end(h, Q);
+      if (t_needs && !attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
     }
     if (k + 1 >= nblk) return GPX_OK;   // border rows only: nothing left to update
-    // its own record for T: the bulk update must not wait for the column kernels below (with one shared record
-    // after them the N = 4096 step went from 1.90 to 2.17 ms: the early, bulk-bound phase starts every update late)
-    if (k == group_end && nblk - (k + 3) > 0) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
 
     // columns k+1 (below its diagonal block; panel k) and k+2 (every panel since T's last step), rows from
     // block row k+2 down
     const int64_t rr = (k + 2) * nb, mr = rows - rr;
     const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
+    bool far_attached = false;
     if (mr > 0) {
       if (h->gram_pending && k >= 1) {   // columns >= 3 were built on T (split gram build)
         GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_gram, 0));
@@ -777,8 +786,9 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
         q_waited_t = last_t;
       }
-      auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan) -> int {
+      auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last) -> int {
         GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= rr, -= panels [kfirst, kfirst+npan)
+        if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
         t.A = L + rr * ld + kfirst * nb; t.lda = ld;
         t.B = L + cfirst * nb * ld + kfirst * nb; t.ldb = ld;
         t.C = A + rr * ld + cfirst * nb; t.ldc = ld;
@@ -794,13 +804,13 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       };
       const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
       if (npan2 > 1 && ncb > 1) {
-        GPX_RET(col_update(k + 1, 1, k, 1));
-        GPX_RET(col_update(k + 2, 1, last_t + 1, npan2));
+        GPX_RET(col_update(k + 1, 1, k, 1, false));
+        GPX_RET(col_update(k + 2, 1, last_t + 1, npan2, true));
       } else {
-        GPX_RET(col_update(k + 1, ncb, k, 1));
+        GPX_RET(col_update(k + 1, ncb, k, 1, true));
       }
     }
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
+    if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
     far_rec[(size_t)k].store(1, std::memory_order_release);
 
     // T: bulk, columns >= k+3, panels last_t+1 .. k in one pass
@@ -817,10 +827,11 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
         t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
         const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
+        if (attach) t.stop_event = h->ev_trail[(size_t)k];
         prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
         GPX_RET(launch_gemm_nt(h, T, t));
         prof_end(h, T);
-        GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
+        if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
         t_pending[(size_t)k] = 1;
       }
       last_t = k;

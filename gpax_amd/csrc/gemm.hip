@@ -485,12 +485,14 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     dim3 pg((unsigned)(ntiles < slots ? ntiles : slots));
     hipLaunchKernelGGL(gemm_nt_persist_kernel, pg, dim3(256), 0, s, g, (int)ntj, ntiles);
     GPX_HIP_CHECK(h, hipGetLastError());
+    if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
   }
   if (!L.small_tile && L.variant == 2 && L.M % 128 == 0 && L.N % 128 == 0) {
     dim3 g128((unsigned)(L.N / 128), (unsigned)(L.M / 128));
     hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), g128, dim3(256), 0, s, g);
     GPX_HIP_CHECK(h, hipGetLastError());
+    if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
   }
   if (!L.small_tile && L.variant == 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && gemm_tile_map_enabled()) {
@@ -510,12 +512,14 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     const int64_t rounds = (g.map_nsuper + 7) / 8;
     hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)(rounds * 8 * S * S)), dim3(256), 0, s, g);
     GPX_HIP_CHECK(h, hipGetLastError());
+    if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
   }
-  if (L.small_tile && L.K == 128) hipLaunchKernelGGL((gemm_nt_onepass_kernel<128>), grid, dim3(256), 0, s, g);
-  else if (L.small_tile && L.K == 64) hipLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, g);
-  else if (L.small_tile) hipLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, s, g);
+  hipEvent_t se = L.stop_event;
+  if (L.small_tile && L.K == 128) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<128>), grid, dim3(256), 0, s, nullptr, se, 0, g);
+  else if (L.small_tile && L.K == 64) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, nullptr, se, 0, g);
+  else if (L.small_tile) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, nullptr, se, 0, g);
+  else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, s, nullptr, se, 0, g);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

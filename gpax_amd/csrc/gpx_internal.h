@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <atomic>
@@ -79,12 +80,15 @@ struct GemmLaunch {
   int variant = 0;      // 64x64 path: 0 = one workgroup per tile, 1 = persistent tile-pipelined kernel
   int cyc_P = 1, cyc_r = 0, cyc_nb = 128;   // block-cyclic local->global row map for the `lower` test (distributed path)
   int a_upper_tri = 0;  // A[m][k] = 0 for k < m: skip the dead K range below each tile's first row (64x64 path)
+  // completion event attached to the kernel's own dispatch (hipExtLaunchKernelGGL stopEvent): no separate
+  // barrier packet behind the kernel (tools/sync_cost: 3.7 -> 2.3 us to the next kernel of the stream)
+  hipEvent_t stop_event = nullptr;
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
 
 // Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda,
-                      double* L, int64_t ldl, double* W, int* info, int col0);
+                      double* L, int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event = nullptr);
 
 // y[0:ncols) = beta*y + alpha * x[0:nrows)^T A[0:nrows, 0:ncols)
 int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, int nrows, int64_t ncols,

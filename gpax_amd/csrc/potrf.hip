@@ -550,13 +550,13 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
 }
 
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda, double* L,
-                      int64_t ldl, double* W, int* info, int col0) {
+                      int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event) {
   switch (nb) {
     case 64:
-      hipLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, A, lda, L, ldl, W, info, col0);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0);
       break;
     case 128:
-      hipLaunchKernelGGL((potrf_diag_kernel<128, 8>), dim3(1), dim3(512), 0, s, A, lda, L, ldl, W, info, col0);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), dim3(1), dim3(512), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

@@ -1,6 +1,7 @@
 // What a stream-ordering operation between two dependent kernels costs on the stream it sits in (gfx950):
 // kernel A (one workgroup, ~20 us) ; <op> ; kernel B -- gap = B's first s_memrealtime - A's last one.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -19,6 +20,25 @@ __global__ void multi(unsigned long long* t, int slot, int spin_us) {   // 64 wo
   if (threadIdx.x == 0 && blockIdx.x == 0) t[2 * slot] = t0;
   while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_us * 100ull) { }
   if (threadIdx.x == 0 && blockIdx.x == 0) t[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+}
+// like potrf_diag's tail: one 512-thread workgroup that ends by storing `kb` KB, then stamps its last instruction
+__global__ __launch_bounds__(512) void tail_store(unsigned long long* t, int slot, int spin_us, double* dst, int kb) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) t[2 * slot] = t0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_us * 100ull) { }
+  for (int i = threadIdx.x; i < kb * 128; i += 512) dst[i] = (double)i;
+  if (threadIdx.x == 0) t[2 * slot + 1] = __builtin_amdgcn_s_memrealtime();
+}
+// background load on another stream: `nwg` workgroups streaming read-modify-write over a big buffer for ~`us` us
+__global__ __launch_bounds__(256) void background(double* buf, size_t n, int us, int dirty) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)us * 100ull) {
+    if (dirty) buf[i] = buf[i] + 1.0; else acc += buf[i];
+    i += (size_t)gridDim.x * 256; if (i >= n) i -= n;
+  }
+  if (acc == 12345.678) buf[0] = acc;
 }
 int main() {
   hipStream_t P, Q; int lo, hi; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -58,6 +78,70 @@ int main() {
     }
     std::sort(gaps.begin(), gaps.end());
     printf("%-50s gap median %.2f us (min %.2f, max %.2f)\n", names[op], gaps[gaps.size() / 2], gaps.front(), gaps.back());
+  }
+  double* dst; CK(hipMalloc(&dst, 1 << 20));
+  {   // stopEvent attached to the kernel itself (hipExtLaunchKernelGGL) instead of a separate hipEventRecord
+    hipEvent_t se; CK(hipEventCreateWithFlags(&se, hipEventDisableTiming | hipEventDisableSystemFence));
+    for (int variant = 0; variant < 2; ++variant) {
+      std::vector<double> gaps, qlag;
+      for (int rep = 0; rep < 12; ++rep) {
+        if (variant == 0) {
+          hipLaunchKernelGGL(tail_store, dim3(1), dim3(512), 0, P, t, 0, 20, dst, 34);
+          CK(hipEventRecord(se, P));
+        } else {
+          hipExtLaunchKernelGGL(tail_store, dim3(1), dim3(512), 0, P, nullptr, se, 0, t, 0, 20, dst, 34);
+        }
+        CK(hipStreamWaitEvent(Q, se, 0));
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, Q, t, 2, 1);          // consumer on the other stream
+        hipLaunchKernelGGL(multi, dim3(16), dim3(256), 0, P, t, 1, 5);       // next kernel on the same stream
+        CK(hipStreamSynchronize(P)); CK(hipStreamSynchronize(Q));
+        unsigned long long h[6]; CK(hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost));
+        if (rep >= 2) { gaps.push_back((double)(h[2] - h[1]) / 100.0); qlag.push_back(((double)h[4] - (double)h[1]) / 100.0); }
+      }
+      std::sort(gaps.begin(), gaps.end()); std::sort(qlag.begin(), qlag.end());
+      printf("%s: same-stream gap median %.2f us; other-stream consumer starts %.2f us after the producer's end (min %.2f)\n",
+             variant ? "stopEvent on the kernel (hipExtLaunchKernelGGL)" : "kernel + hipEventRecord                        ",
+             gaps[gaps.size() / 2], qlag[qlag.size() / 2], qlag.front());
+    }
+  }
+  {
+    hipStream_t T; CK(hipStreamCreateWithPriority(&T, hipStreamNonBlocking, lo));
+    const size_t nbig = (size_t)1 << 26;   // 512 MB
+    double* big; CK(hipMalloc(&big, nbig * 8)); CK(hipMemset(big, 0, nbig * 8));
+    for (int mode = 0; mode < 4; ++mode) {   // 0 none, 1 read-only background, 2 read-modify-write background, 3 rmw, few WGs
+      std::vector<double> gaps;
+      for (int rep = 0; rep < 12; ++rep) {
+        if (mode == 1) hipLaunchKernelGGL(background, dim3(1024), dim3(256), 0, T, big, nbig, 200, 0);
+        if (mode == 2) hipLaunchKernelGGL(background, dim3(1024), dim3(256), 0, T, big, nbig, 200, 1);
+        if (mode == 3) hipLaunchKernelGGL(background, dim3(128), dim3(256), 0, T, big, nbig, 200, 1);
+        hipLaunchKernelGGL(kern, dim3(1), dim3(64), 0, P, t, 2, 40);   // let the background get going
+        hipLaunchKernelGGL(tail_store, dim3(1), dim3(512), 0, P, t, 0, 20, dst, 34);
+        CK(hipEventRecord(evs[2], P));
+        hipLaunchKernelGGL(multi, dim3(16), dim3(256), 0, P, t, 1, 5);
+        CK(hipStreamSynchronize(P)); CK(hipStreamSynchronize(T));
+        unsigned long long h[4]; CK(hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost));
+        if (rep >= 2) gaps.push_back((double)(h[2] - h[1]) / 100.0);
+      }
+      std::sort(gaps.begin(), gaps.end());
+      const char* bn[] = {"idle GPU", "1024-WG streaming READ kernel on another stream", "1024-WG streaming READ-MODIFY-WRITE kernel on another stream", "128-WG streaming READ-MODIFY-WRITE kernel on another stream"};
+      printf("34 KB tail + event record -> 16-WG kernel, %s: gap median %.2f us (min %.2f, max %.2f)\n", bn[mode], gaps[gaps.size() / 2], gaps.front(), gaps.back());
+    }
+  }
+  for (int kb : {0, 2, 34, 256}) {
+    for (int with_record = 0; with_record < 2; ++with_record) {
+      std::vector<double> gaps;
+      for (int rep = 0; rep < 12; ++rep) {
+        hipLaunchKernelGGL(tail_store, dim3(1), dim3(512), 0, P, t, 0, 20, dst, kb);
+        if (with_record) CK(hipEventRecord(evs[2], P));
+        hipLaunchKernelGGL(multi, dim3(16), dim3(256), 0, P, t, 1, 5);
+        CK(hipStreamSynchronize(P));
+        unsigned long long h[4]; CK(hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost));
+        if (rep >= 2) gaps.push_back((double)(h[2] - h[1]) / 100.0);
+      }
+      std::sort(gaps.begin(), gaps.end());
+      printf("one 512-thread WG ending with %3d KB of stores%s -> 16-WG kernel: gap median %.2f us (min %.2f, max %.2f)\n", kb,
+             with_record ? ", event record," : "", gaps[gaps.size() / 2], gaps.front(), gaps.back());
+    }
   }
   return 0;
 }
