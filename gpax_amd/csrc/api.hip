@@ -216,6 +216,7 @@ static hipError_t create_streams(gpx_handle* h) {
   hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
   if (e != hipSuccess) return e;
   if ((e = hipStreamCreateWithPriority(&h->s_main, hipStreamNonBlocking, hi)) != hipSuccess) return e;
+  if ((e = hipStreamCreateWithPriority(&h->s_main2, hipStreamNonBlocking, hi)) != hipSuccess) return e;
   const char* env = getenv("GPX_RESERVED_CUS");
   const int ncu = h->prop.multiProcessorCount;
   int drop = env ? atoi(env) : 0;   // measured: no gain once the bulk kernel is released after the near look-ahead
@@ -226,8 +227,11 @@ static hipError_t create_streams(gpx_handle* h) {
       const bool excluded = ((int64_t)i * drop / ncu) != ((int64_t)(i + 1) * drop / ncu);
       if (!excluded) mask[(size_t)i / 32] |= 1u << (i % 32);
     }
+    // only the bulk stream T is kept off the reserved CUs (GPX_RESERVED_Q=1: the panel stream Q too)
+    const bool mask_q = getenv("GPX_RESERVED_Q") && atoi(getenv("GPX_RESERVED_Q")) != 0;
     hipError_t e1 = hipExtStreamCreateWithCUMask(&h->s_trail, (uint32_t)mask.size(), mask.data());
-    hipError_t e2 = hipExtStreamCreateWithCUMask(&h->s_far, (uint32_t)mask.size(), mask.data());
+    hipError_t e2 = mask_q ? hipExtStreamCreateWithCUMask(&h->s_far, (uint32_t)mask.size(), mask.data())
+                           : hipStreamCreateWithPriority(&h->s_far, hipStreamNonBlocking, hi);
     if (e1 == hipSuccess && e2 == hipSuccess) return hipSuccess;
     if (e1 == hipSuccess) { (void)hipStreamDestroy(h->s_trail); h->s_trail = nullptr; }
     if (e2 == hipSuccess) { (void)hipStreamDestroy(h->s_far); h->s_far = nullptr; }
@@ -273,6 +277,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_PAIR_MIN"))) h->pair_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
+  if ((env = getenv("GPX_RESIDENT"))) h->resident = atoi(env) != 0;
   *out = h;
   return GPX_OK;
 }
@@ -302,6 +307,9 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   for (auto e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   if (h->s_main) (void)hipStreamDestroy(h->s_main);
+  if (h->s_main2) (void)hipStreamDestroy(h->s_main2);
+  if (h->ev_chain2) (void)hipEventDestroy(h->ev_chain2);
+  if (h->d_flags) (void)hipFree(h->d_flags);
   if (h->s_trail) (void)hipStreamDestroy(h->s_trail);
   if (h->s_far) (void)hipStreamDestroy(h->s_far);
   delete h;
@@ -337,6 +345,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "pair_min")) { h->pair_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
+  if (!strcmp(name, "resident")) { h->resident = value != 0; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -350,6 +359,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "pair_min")) { *value = h->pair_min; return GPX_OK; }
   if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
+  if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -522,6 +532,9 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
   if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
   if (!h->ev_fork) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_fork, fl));
   if (!h->ev_gram) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_gram, fl));
+  if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
+  GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, (int64_t)std::max<size_t>(nblk, 64)));
+  GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, 2 * (int64_t)h->nb * h->nb));
   while (h->ev_far.size() < nblk) {
     hipEvent_t a, b;
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, fl));
@@ -529,7 +542,6 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
     h->ev_far.push_back(a);
     h->ev_w.push_back(b);
   }
-  GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, (int64_t)h->nb * h->nb));
   while (h->ev_panel.size() < nblk) {
     hipEvent_t a, b;
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, fl));
@@ -663,7 +675,7 @@ static int factor_loop(gpx_handle* h, int64_t rows_total, int64_t tri_base = -1)
 static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base) {
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld, nblk = npad / nb;
   hipStream_t P = h->s_main, Q = h->s_far, T = h->s_trail;
-  double* A = h->d_A; double* L = h->d_L; double* S = h->d_mini;
+  double* A = h->d_A; double* L = h->d_L;
   auto rows_at = [&](int64_t k) -> int64_t {
     return tri_base >= 0 ? std::min<int64_t>(rows_total, tri_base + (k + 1) * nb) : rows_total;
   };
@@ -677,9 +689,19 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   // of g at a group boundary needs no fix-up.
   // Q and T fork from P once up front (inside a stream capture a stream must join from the origin stream
   // first; joining T through an event recorded on Q crashed hipStreamEndCapture on ROCm 7.2)
+  // Resident start of potrf_diag: consecutive diagonal blocks alternate between two chain streams, so
+  // potrf_diag(k+1) is dispatched while block k is still being worked on, owns its CU early and sleeps on the
+  // tile counter that the A -= S S^T kernel of step k publishes (potrf.hip).  Behind a saturating bulk update a
+  // freshly launched potrf_diag waits 20-30 us for a CU to drain (it needs all of its LDS): this removes that
+  // wait from the first ~11 block columns and the launch gap from all of them.
+  const bool resident = h->resident != 0 && !h->in_capture && !h->prof_mode && nblk >= 3;
+  hipStream_t P2 = resident ? h->s_main2 : P;
+  const unsigned n_signal = (unsigned)((nb / 32) * (nb / 32 + 1) / 2);   // lower 32x32 tiles of a diagonal block
+  if (resident) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)nblk * sizeof(unsigned), P));
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
+  if (resident) GPX_HIP_CHECK(h, hipStreamWaitEvent(P2, h->ev_join, 0));
 
   // Host-side hand-shake between the two enqueueing threads: an event may only be waited for after the call
   // that records it has been ISSUED (a wait on a not-yet-recorded event is a no-op).
@@ -700,6 +722,8 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
 
   // ---- the chain (stream P) at step k: potrf, then the diagonal band
   auto chain = [&](int64_t k) -> int {
+    hipStream_t P = (resident && (k & 1)) ? P2 : h->s_main;   // this step's chain stream (shadows the outer P)
+    double* S = h->d_mini + (k & 1) * nb * nb;
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
     // ev_w[k] = completion of potrf_diag(k): attached to the kernel's own dispatch when possible (no barrier
     // packet behind it), else recorded right after it -- NOT after the two band kernels (measured 1.91 -> 2.12 ms
@@ -707,7 +731,8 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     const bool need_w = rows - r0 > 0;
     prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
     GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
-                              h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr));
+                              h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr,
+                              (resident && k >= 1) ? h->d_flags + (k - 1) : nullptr, n_signal));
     prof_end(h, P);
     if (!need_w) return GPX_OK;
     if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
@@ -731,6 +756,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     u.C = A + r0 * ld + r0; u.ldc = ld;
     u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
     u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
+    if (resident) u.signal = h->d_flags + k;   // potrf_diag(k+1) is already resident and polls this counter
     prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
     GPX_RET(launch_gemm_nt(h, P, u));
     prof_end(h, P);
@@ -858,6 +884,10 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     }
   }
   GPX_RET(rc);
+  if (resident) {
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_chain2, P2));
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_chain2, 0));
+  }
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));

@@ -34,6 +34,7 @@ struct GemmArgs {
   // block-cyclic row distribution (distributed factorisation): local row m is global row
   // ((m / cyc_nb) * cyc_P + cyc_r) * cyc_nb + m % cyc_nb;  cyc_P <= 1: rows are global already
   int cyc_P, cyc_r, cyc_nb;
+  unsigned* signal;   // one-pass path: publish the stored tile to an already-resident consumer (see GemmLaunch::signal)
 };
 
 // first global row of the tile whose first (local) row is row_off + m0
@@ -443,6 +444,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc1, 0, 0, 0);
     }
   }
+  if (g.signal) {
+    // publish: write-through (sc1) stores, each wave drains its own, the barrier collects the four waves, ONE
+    // lane adds to the agent-scope counter the resident consumer polls
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = g.alpha * (acc0[r] + acc1[r]);
+      if (g.beta != 0.0) v += g.beta * cin[r];
+      __hip_atomic_store(&cp[(int64_t)(4 * r) * g.ldc], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     double v = g.alpha * (acc0[r] + acc1[r]);
@@ -472,6 +487,11 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   g.a_upper_tri = L.a_upper_tri;
   g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
+  g.signal = L.signal;
+  if (L.signal && !(L.small_tile && (L.K == 128 || L.K == 64))) {
+    gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel only");
+    return GPX_ERR_ARG;
+  }
   if (L.a_upper_tri && (L.small_tile || L.variant != 0)) {
     gpx_set_error(h, "gemm_nt: a_upper_tri is served by the 64x64 kernel only");
     return GPX_ERR_ARG;

@@ -83,12 +83,16 @@ struct GemmLaunch {
   // completion event attached to the kernel's own dispatch (hipExtLaunchKernelGGL stopEvent): no separate
   // barrier packet behind the kernel (tools/sync_cost: 3.7 -> 2.3 us to the next kernel of the stream)
   hipEvent_t stop_event = nullptr;
+  // one-pass (32x32-tile) path: every workgroup that stores a tile publishes it (write-through stores, then one
+  // agent-scope add to this counter) for a consumer that is already resident (potrf_diag's resident start)
+  unsigned* signal = nullptr;
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
 
 // Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda,
-                      double* L, int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event = nullptr);
+                      double* L, int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event = nullptr,
+                      const unsigned* wait_flag = nullptr, unsigned wait_count = 0);
 
 // y[0:ncols) = beta*y + alpha * x[0:nrows)^T A[0:nrows, 0:ncols)
 int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, int nrows, int64_t ncols,
@@ -176,6 +180,10 @@ struct StageProf {
 struct gpx_handle {
   int device = 0;
   hipStream_t s_main = nullptr, s_trail = nullptr, s_far = nullptr;
+  hipStream_t s_main2 = nullptr;   // second chain stream: consecutive diagonal blocks alternate, so the next potrf_diag can already be resident
+  unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per-step tile counters of the resident start
+  hipEvent_t ev_chain2 = nullptr;
+  int resident = 0;                // 1: resident start of potrf_diag in the split-panel schedule (measured: no gain, the early steps wait for the bulk update, not for a CU)
   std::string err;
   hipDeviceProp_t prop;
 

@@ -410,10 +410,11 @@ void tl_set_potrf(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #endif
 
 template <int NB, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* __restrict__ A,
+__global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A,
                                                                  int64_t lda, double* __restrict__ L,
                                                                  int64_t ldl, double* __restrict__ W,
-                                                                 int* info, int col0) {
+                                                                 int* info, int col0, const unsigned* wait_flag,
+                                                                 unsigned wait_count) {
   constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
   __shared__ double sm[2 * NTRI * 256 + LEAF_SHARE_DOUBLES];
   double* Lt = sm;
@@ -422,6 +423,25 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
+  // Resident start (split-panel schedule): the kernel is launched a whole step early, so that it already owns a
+  // CU (it needs all of its LDS, and behind a saturating bulk update a freshly launched one waits 20-30 us for a
+  // CU to drain), and sleeps here until the `wait_count` workgroups of the preceding A_kk -= S S^T kernel have
+  // published their tiles (write-through stores + an agent-scope counter, gemm.hip).  One lane polls, relaxed;
+  // ONE agent-scope acquire after the match drops this CU's stale lines; then the barrier releases the loads.
+  // The spin is bounded (2 s of s_memrealtime): on a timeout the block reports info = -7 and carries on.
+  if (wait_flag) {
+    POTRF_TL(5, col0);
+    if (tid == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_count) {
+        __builtin_amdgcn_s_sleep(8);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { atomicMin(info, -7); break; }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
   POTRF_TL(1, col0);
   GPX_STAMP(0);
   for (int t = tid; t < LEAF_SHARE_DOUBLES; t += NWAVES * 64) sh[t] = 0.0;   // epochs start at 0
@@ -550,13 +570,14 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* _
 }
 
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda, double* L,
-                      int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event) {
+                      int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event, const unsigned* wait_flag,
+                      unsigned wait_count) {
   switch (nb) {
     case 64:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count);
       break;
     case 128:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), dim3(1), dim3(512), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), dim3(1), dim3(512), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

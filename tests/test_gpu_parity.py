@@ -241,6 +241,31 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
     assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
 
 
+@pytest.mark.parametrize("option,value", [("resident", 1), ("host_threads", 2)])
+def test_optional_schedule_features_match_the_default(core, option, value):
+    """Two optional features of the split-panel schedule, off by default because they measured no gain: the
+    resident start of potrf_diag (in-kernel hand-off from the A -= S S^T tiles through write-through stores and
+    an agent-scope counter) and the second enqueueing host thread.  Same bits as the default schedule."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, y, xn, p = orc.synthetic_problem(1500, 6, 90, seed=31)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    core.set_train(x)
+    core.set_test(xn)
+    _, _, l0 = core.fit_factor(prm, want_l=True)
+    info0, logp0, mean0, var0 = core.fit_predict(prm, y - 1.0, np.ones(90), 0.0)
+    core.set_option(option, value)
+    for _ in range(3):
+        _, _, l1 = core.fit_factor(prm, want_l=True)
+        info1, logp1, mean1, var1 = core.fit_predict(prm, y - 1.0, np.ones(90), 0.0)
+        assert info0 == 0 and info1 == 0
+        assert np.array_equal(l0, l1) and logp0 == logp1 and np.array_equal(mean0, mean1) and np.array_equal(var0, var1)
+    core.set_option(option, 0 if option == "resident" else 1)
+    logp_ref, mean_ref, var_ref = orc.fit_predict(orc.RBF, x, y, xn, p)
+    assert abs(logp1 - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+
+
 def test_full_size_properties(core):
     """BASELINE config C2 (N=4096, d=8, RBF, M=1000) through size-independent properties:
     K symmetric, L L^T = K, logp and posterior against the oracle (LAPACK, ~1 s)."""

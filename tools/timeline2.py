@@ -37,10 +37,10 @@ rec = rec[np.argsort(rec[:, 1])]
 t0 = rec[0, 1]
 us = (rec[:, 1] - t0) / 100.0
 nb = 128
-names = {1: "potrf start", 2: "potrf end"}
+names = {1: "potrf start", 2: "potrf end", 5: "potrf resident"}
 rows = []
 for (kind, _, a, b), t in zip(rec, us):
-    if kind in (1, 2):
+    if kind in (1, 2, 5):
         rows.append((t, names[kind], f"k={a // nb}"))
     elif kind == 3:
         N_, beta = b // 1000000, b % 1000000
@@ -52,7 +52,7 @@ print(f"{cnt} records; step spans {us[-1]:.1f} us from first to last logged star
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (12, 15)
 show = False
 for t, what, info in rows:
-    if what == "potrf start":
+    if what in ("potrf start", "potrf resident"):
         k = int(info[2:])
         show = lo <= k <= hi
     if show:
