@@ -278,6 +278,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   if ((env = getenv("GPX_RESIDENT"))) h->resident = atoi(env) != 0;
+  if ((env = getenv("GPX_WINDOW"))) h->window = atoi(env) >= 3 ? 3 : 2;
   *out = h;
   return GPX_OK;
 }
@@ -346,6 +347,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = value != 0; return GPX_OK; }
+  if (!strcmp(name, "window")) { h->window = value >= 3 ? 3 : 2; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -360,6 +362,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
+  if (!strcmp(name, "window")) { *value = h->window; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -789,7 +792,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
       // T gets its own event on the panel: the bulk update must not wait for the column kernels below (with one
       // shared event after them the N = 4096 step went from 1.90 to 2.17 ms: every bulk update starts late)
-      const bool t_needs = k + 1 < nblk && k == group_end && nblk - (k + 3) > 0;
+      const bool t_needs = k + 1 < nblk && k == group_end && nblk - (k + 1 + (h->window >= 3 ? 3 : 2)) > 0;
       if (t_needs && attach) g.stop_event = h->ev_panel[(size_t)k];
       prof_begin(h, Q, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
       GPX_RET(launch_gemm_nt(h, Q, g));
@@ -798,54 +801,82 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     }
     if (k + 1 >= nblk) return GPX_OK;   // border rows only: nothing left to update
 
-    // columns k+1 (below its diagonal block; panel k) and k+2 (every panel since T's last step), rows from
-    // block row k+2 down
+    // Q's window of `w` columns.  w = 2: columns k+1 (panel k) and k+2 (every panel since T's last step).
+    // w = 3: columns k+1, k+2 (panel k; both were in the window at step k-1) -> ev_far, THEN column k+3 enters
+    // the window with every panel since T's last step.  With w = 3 nothing P waits for depends on T any more
+    // (P(k+1) <- Q(k) first kernel <- Q(k-1) second kernel <- T), which gives T one more step of slack: enough to
+    // group the bulk updates in the bulk-bound first steps of a small matrix too.
+    const int w = h->window >= 3 ? 3 : 2;
     const int64_t rr = (k + 2) * nb, mr = rows - rr;
-    const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
     bool far_attached = false;
-    if (mr > 0) {
-      if (h->gram_pending && k >= 1) {   // columns >= 3 were built on T (split gram build)
+    auto wait_gram = [&]() -> int {
+      if (h->gram_pending) {   // columns >= 3 were built on T (split gram build)
         GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_gram, 0));
         h->gram_pending = false;
       }
-      if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {   // column k+2 was last written there
+      return GPX_OK;
+    };
+    auto wait_bulk = [&]() -> int {   // the column entering the window was last written by T's step last_t
+      if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {
         GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
         q_waited_t = last_t;
       }
-      auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last) -> int {
-        GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= rr, -= panels [kfirst, kfirst+npan)
-        if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
-        t.A = L + rr * ld + kfirst * nb; t.lda = ld;
-        t.B = L + cfirst * nb * ld + kfirst * nb; t.ldb = ld;
-        t.C = A + rr * ld + cfirst * nb; t.ldc = ld;
-        t.M = mr; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-        t.lower = 1; t.row_off = rr; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 1;
-        double entries = 0.0;
-        for (int64_t c = cfirst; c < cfirst + ncol; ++c)
-          entries += (c * nb >= rr) ? (double)nb * (nb + 1) / 2.0 + (double)(mr - nb) * nb : (double)mr * nb;
-        prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(mr + ncol * nb) * t.K));
-        int rc = launch_gemm_nt(h, Q, t);
-        prof_end(h, Q);
-        return rc;
-      };
-      const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
-      if (npan2 > 1 && ncb > 1) {
-        GPX_RET(col_update(k + 1, 1, k, 1, false));
-        GPX_RET(col_update(k + 2, 1, last_t + 1, npan2, true));
-      } else {
-        GPX_RET(col_update(k + 1, ncb, k, 1, true));
+      return GPX_OK;
+    };
+    auto col_update = [&](int64_t r_first, int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last) -> int {
+      GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= r_first, -= panels [kfirst, kfirst+npan)
+      const int64_t mrr = rows - r_first;
+      if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
+      t.A = L + r_first * ld + kfirst * nb; t.lda = ld;
+      t.B = L + cfirst * nb * ld + kfirst * nb; t.ldb = ld;
+      t.C = A + r_first * ld + cfirst * nb; t.ldc = ld;
+      t.M = mrr; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
+      t.lower = 1; t.row_off = r_first; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 1;
+      double entries = 0.0;
+      for (int64_t c = cfirst; c < cfirst + ncol; ++c)
+        entries += (c * nb >= r_first) ? (double)nb * (nb + 1) / 2.0 + (double)(mrr - nb) * nb : (double)mrr * nb;
+      prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(mrr + ncol * nb) * t.K));
+      int rc = launch_gemm_nt(h, Q, t);
+      prof_end(h, Q);
+      return rc;
+    };
+    const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
+    if (w == 2) {
+      if (mr > 0) {
+        if (k >= 1) GPX_RET(wait_gram());
+        GPX_RET(wait_bulk());
+        const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
+        if (npan2 > 1 && ncb > 1) {
+          GPX_RET(col_update(rr, k + 1, 1, k, 1, false));
+          GPX_RET(col_update(rr, k + 2, 1, last_t + 1, npan2, true));
+        } else {
+          GPX_RET(col_update(rr, k + 1, ncb, k, 1, true));
+        }
+      }
+      if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
+      far_rec[(size_t)k].store(1, std::memory_order_release);
+    } else {
+      if (mr > 0) {
+        if (k >= 1) GPX_RET(wait_gram());
+        GPX_RET(col_update(rr, k + 1, ncb, k, 1, true));
+      }
+      if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
+      far_rec[(size_t)k].store(1, std::memory_order_release);
+      const int64_t r3 = (k + 3) * nb;
+      if (k + 3 < nblk && rows - r3 > 0) {
+        GPX_RET(wait_gram());
+        GPX_RET(wait_bulk());
+        GPX_RET(col_update(r3, k + 3, 1, last_t + 1, k - last_t, false));
       }
     }
-    if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
-    far_rec[(size_t)k].store(1, std::memory_order_release);
 
-    // T: bulk, columns >= k+3, panels last_t+1 .. k in one pass
-    const int64_t nbulk = nblk - (k + 3);
+    // T: bulk, columns >= k+1+w, panels last_t+1 .. k in one pass
+    const int64_t nbulk = nblk - (k + 1 + w);
     if (k == group_end) {
       if (nbulk > 0) {
         GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
         const int64_t kfirst = last_t + 1, npan = k - last_t;
-        const int64_t cf = k + 3, br = cf * nb, bm = rows - br, nc = nbulk * nb;
+        const int64_t cf = k + 1 + w, br = cf * nb, bm = rows - br, nc = nbulk * nb;
         GemmLaunch t;
         t.A = L + br * ld + kfirst * nb; t.lda = ld;
         t.B = L + br * ld + kfirst * nb; t.ldb = ld;
@@ -1434,7 +1465,7 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
     // d_hyp / d_noise / d_r / d_mnew, so the same graph is replayed for every hyper-parameter draw.
     char key[512];
     snprintf(key, sizeof(key), "%d|%d|%lld|%lld|%d|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p", fp.kind, fp.apply_noise,
-             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth + 16 * h->pair_min + 4096 * h->quad_min, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
+             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth + 16 * h->pair_min + 4096 * h->quad_min + 1000000 * h->window, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
              (void*)h->d_x, (void*)h->d_xnew, (void*)h->d_r, (void*)(h->have_mnew ? h->d_mnew : nullptr),
              (void*)h->d_hyp, (void*)fp.noise_dev, (void*)h->d_mean, (void*)h->d_z);
     auto it = h->graphs.find(key);

@@ -192,6 +192,7 @@ struct gpx_handle {
   int lookahead = 1;
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 32;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
+  int window = 2;      // split-panel schedule: block columns the panel stream keeps current ahead of the chain (2 | 3)
   int quad_min = 48;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
