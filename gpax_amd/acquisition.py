@@ -20,6 +20,11 @@ def split_array(x, s):
     return [x[i : i + s] for i in range(0, len(x), s)]
 
 
+def x_shape_err_msg(x, desired_dims):
+    """gpax/acquisition.py:31-40."""
+    return f"x of shape {tuple(np.shape(x))} must have dimensions {tuple(desired_dims)}"
+
+
 class AcquisitionFunction:
     """gpax/acquisition.py:42-223 (analytic q=1 path and the Halton optimiser)."""
 
@@ -51,20 +56,30 @@ class AcquisitionFunction:
         result = model.sample(x.reshape(-1, d), fast=self.fast)
         return result.y.reshape(-1, n, self.q)
 
+    def _monte_carlo_evaluation(self, model, x):
+        """gpax/acquisition.py:104-119: the integrand averaged over the GP samples."""
+        if x.ndim == 2 and self.q == 1:
+            x = x.reshape(x.shape[0], 1, x.shape[-1])
+        if x.ndim != 3 or x.shape[1] != self.q:
+            raise ValueError(x_shape_err_msg(x, ("N", "q", "d")))
+        return self._integrand(model, x).mean(axis=0)
+
+    def _analytic_evaluation(self, model, x):
+        """gpax/acquisition.py:121-131."""
+        if self.q > 1:
+            raise ValueError("Cannot evaluate analytic expression for q!=1")
+        if x.ndim == 3 and x.shape[1] == 1:
+            x = x.reshape(x.shape[0], x.shape[-1])
+        if x.ndim != 2:
+            raise ValueError(x_shape_err_msg(x, ("N", "d")))
+        return self._analytic(model, x)
+
     def __call__(self, model, x):
         """gpax/acquisition.py:133-164."""
         x = np.asarray(x, dtype=np.float64)
         if self.force_monte_carlo or self.q > 1:
-            if x.ndim == 2 and self.q == 1:
-                x = x.reshape(x.shape[0], 1, x.shape[-1])
-            if x.ndim != 3 or x.shape[1] != self.q:
-                raise ValueError(f"x of shape {x.shape} must be (N, q, d)")
-            return self._integrand(model, x).mean(axis=0)
-        if x.ndim == 3 and x.shape[1] == 1:
-            x = x.reshape(x.shape[0], x.shape[-1])
-        if x.ndim != 2:
-            raise ValueError(f"x of shape {x.shape} must be (N, d)")
-        return self._analytic(model, x)
+            return self._monte_carlo_evaluation(model, x)
+        return self._analytic_evaluation(model, x)
 
     def _optimize_halton(self, model, n_samples):
         """gpax/acquisition.py:166-216."""

@@ -337,6 +337,30 @@ class GaussianProcess:
         mu, sd, ys = parallel.map_draws(one, n_hp)
         return hp, mu, sd, ys
 
+    # the reference's private sampling entry points (gpax/gp.py:352-397), same names and return values
+    def _sample_prior(self, rng, x_new, condition_on_data, fast):
+        hp, n = self._get_hp_samples_from_prior(rng, fast)
+        return self._sample_over_hps(rng, x_new, hp, n, condition_on_data)
+
+    def _sample_unconditioned_prior(self, rng, x_new, fast):
+        return self._sample_prior(rng, x_new, False, fast)
+
+    def _sample_conditioned_prior(self, rng, x_new, fast):
+        return self._sample_prior(rng, x_new, True, fast)
+
+    def _sample_posterior(self, rng, x_new, fast=True):
+        hp, n = self._get_hp_samples_from_posterior(fast)
+        return self._sample_over_hps(rng, x_new, hp, n, True)
+
+    def _pre_sample(self, x_new):
+        """gpax/gp.py:393-397 (the device_put happens inside the library: gpx_set_test)."""
+        _, rng = state.get_rng_key()
+        return rng, np.asarray(x_new, dtype=np.float64)
+
+    def _fit_transforms(self):
+        """gpax/gp.py:168-193 under its reference name."""
+        self._post_init()
+
     def sample(self, x_new, fast=False):
         """gpax/gp.py:399-462: returns a GPSample with ``y`` of shape (hp, gp, M)."""
         x_new = self.input_transform.forward(x_new, transforms_as="mean")
@@ -541,6 +565,12 @@ class VariationalInferenceGP(GaussianProcess):
             )
             self.hp_samples = 1
 
+    def _print_summary(self):
+        """gpax/gp.py:558-563."""
+        print("\nInferred GP parameters")
+        for k, vals in self.kernel_params["params"].items():
+            print(k, " " * (15 - len(k)), np.around(vals, 4))
+
     def fit(self):
         key, rng = state.get_rng_key()
         space = _ParamSpace(self)
@@ -563,6 +593,8 @@ class VariationalInferenceGP(GaussianProcess):
                 loc, rho = both[:dim], both[dim:]
         self.svi = {"loc": loc, "scale": _softplus(rho), "space": space}
         self.kernel_params = {"params": space.constrain(loc), "losses": losses}
+        if state.verbose > 0:
+            self._print_summary()
         self.metadata["fit_key"] = np.array(key)
         self._is_fit = True
 

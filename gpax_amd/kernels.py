@@ -13,6 +13,22 @@ from gpax_amd import _lib, state
 from gpax_amd.utils.prior_utils import HalfNormal, LogNormal, Parameter, Prior
 
 
+def _add_jitter(x, jitter=1e-6):
+    """gpax/kernels.py:33-36."""
+    return x + jitter
+
+
+def _squared_distance(x1, x2, lengthscale):
+    """gpax/kernels.py:39-51: scaled squared distances.  Built from the HIP gram kernel (the RBF gram with
+    unit scale is exp(-r2/2)), so it is exact only where exp/log round-trips: use for inspection, the
+    factorisation path never materialises distances."""
+    x1 = np.asarray(x1, dtype=np.float64)
+    x2 = np.asarray(x2, dtype=np.float64)
+    params = _lib.make_params(_lib.RBF, 1.0, lengthscale, None, None, 0.0, False)
+    k = state.get_core().gram(params, x1, x2)
+    return -2.0 * np.log(k)
+
+
 class Kernel(Prior):
     """gpax/kernels.py:54-94: base kernel with ``k_noise ~ HalfNormal(0.01)`` and the constant
     ``k_jitter = 1e-6``."""

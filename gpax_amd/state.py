@@ -17,7 +17,9 @@ _cores = {}
 
 
 def set_verbosity(mode="normal"):
-    _this.verbose = _VERBOSITY_LEVELS[mode]
+    """gpax/state.py:18-27."""
+    assert isinstance(mode, str)
+    _this.verbose = _VERBOSITY_LEVELS[mode.lower()]
 
 
 @contextmanager
@@ -28,6 +30,16 @@ def temporary_verbosity(mode):
         yield
     finally:
         _this.verbose = prev
+
+
+def silent_mode():
+    """gpax/state.py:30-43."""
+    return temporary_verbosity("silent")
+
+
+def debug_mode():
+    """gpax/state.py:45-58."""
+    return temporary_verbosity("debug")
 
 
 def set_device(dev):

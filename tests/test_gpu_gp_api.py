@@ -180,3 +180,24 @@ def test_acquisition_ei_ucb_and_factor_reuse():
     assert np.abs(ucb - orc.upper_confidence_bound(mu7, sd7, 4.0)).max() < 1e-12
     x_star, val = ExpectedImprovement(bounds).optimize(gp, 1000)
     assert x_star.shape == (1, 2) and np.isfinite(val) and (x_star >= 0).all() and (x_star <= 3).all()
+
+
+def test_reference_private_sampling_entry_points():
+    """gpax/gp.py:352-397: _sample_*prior / _sample_posterior return (hp, mu, sd, sampled) with the (hp, gp, M)
+    layout, and kernels._squared_distance reproduces the oracle's distances through the HIP gram kernel."""
+    from gpax_amd import kernels, state
+    from gpax_amd.gp import ExactGP
+    from oracle import gp_oracle as orc
+
+    x, y, x_grid = _dummy_sinusoidal_data()
+    state.set_rng_key(3)
+    gp = ExactGP(kernel=kernels.RBFKernel(), x=x, y=y, hp_samples=5, gp_samples=7)
+    rng, xg = gp._pre_sample(gp.input_transform.forward(x_grid[::10], transforms_as="mean"))
+    for fn, n_hp in ((gp._sample_unconditioned_prior, 5), (gp._sample_conditioned_prior, 5)):
+        hp, mu, sd, ys = fn(rng, xg, False)
+        assert ys.shape == (n_hp, 7, xg.shape[0]) and mu.shape == (n_hp, xg.shape[0]) and sd.shape == mu.shape
+        assert set(hp) == {"k_noise", "k_jitter", "k_scale", "k_length"}
+    hp, mu, sd, ys = gp._sample_conditioned_prior(rng, xg, True)
+    assert ys.shape == (1, 7, xg.shape[0])
+    r2 = kernels._squared_distance(x, x[:5], np.array([0.7]))
+    assert np.abs(r2 - orc.squared_distance_direct(x, x[:5], np.array([0.7]))).max() < 1e-9

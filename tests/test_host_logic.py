@@ -227,3 +227,33 @@ def test_adam_matches_the_textbook_update():
     opt = _Adam(2, step_size=0.1, b1=0.5, b2=0.9)
     x = opt.step(np.zeros(2), np.array([1.0, -2.0]))
     assert np.allclose(x, [0.1, -0.1], atol=1e-6)       # first step: m_hat / sqrt(v_hat) = sign(grad)
+
+
+def test_reference_named_helpers_exist():
+    """Names a gpax user may reach for (gpax/gp.py:352-397, gpax/state.py:30-58, gpax/acquisition.py:31-131,
+    gpax/kernels.py:33-51) exist with the reference's signatures."""
+    import inspect
+
+    from gpax_amd import acquisition, gp, kernels, state
+
+    for name in ("_sample_prior", "_sample_unconditioned_prior", "_sample_conditioned_prior", "_sample_posterior",
+                 "_pre_sample", "_fit_transforms", "get_mvn_posterior", "_get_mean_and_covariance",
+                 "_get_mean_and_covariance_unconditioned", "_sample_gp_given_single_hp", "_fast_predict"):
+        assert callable(getattr(gp.GaussianProcess, name)), name
+    assert list(inspect.signature(gp.GaussianProcess._sample_prior).parameters)[1:] == ["rng", "x_new", "condition_on_data", "fast"]
+    assert callable(gp.VariationalInferenceGP._print_summary)
+    for name in ("_monte_carlo_evaluation", "_analytic_evaluation", "_optimize_halton", "optimize"):
+        assert callable(getattr(acquisition.AcquisitionFunction, name)), name
+    assert "must have dimensions ('N', 'd')" in acquisition.x_shape_err_msg(np.zeros((2, 3, 4)), ("N", "d"))
+    assert kernels._add_jitter(1.0, 0.5) == 1.5 and callable(kernels._squared_distance)
+    v = state.verbose
+    with state.silent_mode():
+        assert state.verbose == 0
+    with state.debug_mode():
+        assert state.verbose == 2
+    assert state.verbose == v
+    acq = acquisition.UpperConfidenceBound(np.array([[0.0], [1.0]]), q=2)
+    with pytest.raises(ValueError):
+        acq._analytic_evaluation(None, np.zeros((3, 1)))
+    with pytest.raises(ValueError):
+        acq._monte_carlo_evaluation(None, np.zeros((3, 1)))
