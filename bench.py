@@ -130,6 +130,7 @@ def main():
                     help="draws: independent hyper-parameter draws per rank (default, weak scaling); "
                          "dist: ONE factorisation row-block-cyclic over the ranks with RCCL panel broadcasts (config C4, strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="add a third pass with every launch bracketed: per-stage milliseconds")
     ap.add_argument("--cpu-reps", type=int, default=3)
     args = ap.parse_args()
 
@@ -220,10 +221,11 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel (trailing SYRK/GEMM update on fp64 MFMA), measured with
-        # HIP events on the library's own streams over a second pass of the same K steps (event
-        # brackets on every launch perturb the clock, so they are kept out of `value`'s region).
+        # HIP events on the stream the kernel is launched on, over a second pass of the same K steps
+        # (profile mode 3: only the bulk-update and gram launches are bracketed -- nothing on the chain
+        # stream -- so the brackets stay out of `value`'s region and barely stretch what they measure).
         core.profile_reset()
-        core.profile_mode(1)
+        core.profile_mode(3)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -262,8 +264,17 @@ def main():
             "traffic": _committed_traffic("gram"),
             "avg_launch_us": g_avg * 1e6,
         }
-        out["stage_ms_per_step"] = {k: v["ms"] / args.steps for k, v in stages.items()}
         out["ms_per_step_profiled"] = prof_ms_per_step
+        if args.stages:   # every launch bracketed: per-stage kernel time (this pass stretches the step considerably)
+            core.profile_reset()
+            core.profile_mode(1)
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sync()
+            out["ms_per_step_all_bracketed"] = (time.perf_counter() - t2) / args.steps * 1e3
+            out["stage_ms_per_step"] = {gpax_amd._lib.STAGE_NAMES[i]: core.profile_get(i)["ms"] / args.steps for i in range(8)}
+            core.profile_mode(0)
 
         if not args.no_cpu_baseline:
             # ---- CPU baseline: the oracle (NumPy/SciPy port of the reference formulae; the reference's

@@ -83,9 +83,13 @@ static hipEvent_t prof_event(gpx_handle* h) {
 }
 
 // mode 1: every launch is bracketed; mode 2 (coarse): only the whole step, the gram build and the epilogue --
-// three event pairs per step, so the brackets do not stretch what they measure
+// three event pairs per step, so the brackets do not stretch what they measure; mode 3: only the launches of the
+// two kernels that carry a roofline (bulk update on its own stream, gram build): nothing on the chain stream
 static bool prof_stage_on(const gpx_handle* h, int stage) {
-  return h->prof_mode == 1 || (h->prof_mode == 2 && (stage == GPX_STAGE_FACTOR_TOTAL || stage == GPX_STAGE_GRAM || stage == GPX_STAGE_EPILOGUE));
+  if (h->prof_mode == 1) return true;
+  if (h->prof_mode == 2) return stage == GPX_STAGE_FACTOR_TOTAL || stage == GPX_STAGE_GRAM || stage == GPX_STAGE_EPILOGUE;
+  if (h->prof_mode == 3) return stage == GPX_STAGE_TRAILING || stage == GPX_STAGE_GRAM;   // the two roofline kernels only
+  return false;
 }
 
 void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double bytes) {
@@ -99,6 +103,19 @@ void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double by
   h->prof[stage].flops += flops;
   h->prof[stage].bytes += bytes;
   h->prof[stage].launches += 1;
+}
+
+bool prof_pair(gpx_handle* h, int stage, double flops, double bytes, hipEvent_t* a, hipEvent_t* b) {
+  *a = *b = nullptr;
+  if (!h->prof_mode || !prof_stage_on(h, stage)) return false;
+  gpx_handle::PendingEv p;
+  p.stage = stage; p.a = prof_event(h); p.b = prof_event(h);
+  h->pending.push_back(p);
+  h->prof[stage].flops += flops;
+  h->prof[stage].bytes += bytes;
+  h->prof[stage].launches += 1;
+  *a = p.a; *b = p.b;
+  return true;
 }
 
 void prof_end(gpx_handle* h, hipStream_t s) {
@@ -721,7 +738,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
 
   // completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL stopEvent) except inside a
   // stream capture and under per-launch profiling, where they are recorded behind the kernel as usual
-  const bool attach = !h->in_capture && !h->prof_mode;
+  const bool attach = !h->in_capture && h->prof_mode != 1;
 
   // ---- the chain (stream P) at step k: potrf, then the diagonal band
   auto chain = [&](int64_t k) -> int {
@@ -884,11 +901,12 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
         t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
         const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
-        if (attach) t.stop_event = h->ev_trail[(size_t)k];
-        prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
+        // profiled: the kernel's own dispatch timestamps (what rocprofv3 reports), the hand-over event recorded behind it
+        const bool timed = prof_pair(h, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K),
+                                     &t.start_event, &t.stop_event);
+        if (attach && !timed) t.stop_event = h->ev_trail[(size_t)k];
         GPX_RET(launch_gemm_nt(h, T, t));
-        prof_end(h, T);
-        if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
+        if (!attach || timed) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
         t_pending[(size_t)k] = 1;
       }
       last_t = k;
@@ -981,6 +999,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     GramLaunch c = g;
     c.x1 = h->d_xnew; c.n1 = m_rows; c.out = h->d_A + npad * ld; c.lower_only = 0; c.diag_rule = 0;
     c.noise = nullptr; c.zero_info = nullptr; c.col0 = 0; c.x2 = h->d_x; c.n2 = n;
+    c.start_event = c.stop_event = nullptr;
     prof_begin(h, st, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(fp.kind, d) * m_rows * n,
                8.0 * m_rows * n + 8.0 * (m_rows + n) * d);
     int rc = launch_gram(h, st, c);
@@ -996,9 +1015,8 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   if (!split) {
     g.zero_info = h->d_info;
     gram_cost(0, n, &fl, &by);
-    prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
+    (void)prof_pair(h, GPX_STAGE_GRAM, fl, by, &g.start_event, &g.stop_event);
     GPX_RET(launch_gram(h, s, g));
-    prof_end(h, s);
     if (K_out) {
       GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
                                         (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));

@@ -535,11 +535,11 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
   }
-  hipEvent_t se = L.stop_event;
-  if (L.small_tile && L.K == 128) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<128>), grid, dim3(256), 0, s, nullptr, se, 0, g);
-  else if (L.small_tile && L.K == 64) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, nullptr, se, 0, g);
-  else if (L.small_tile) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, nullptr, se, 0, g);
-  else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, s, nullptr, se, 0, g);
+  hipEvent_t se = L.stop_event, sb = L.start_event;
+  if (L.small_tile && L.K == 128) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<128>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else if (L.small_tile && L.K == 64) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else if (L.small_tile) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, s, sb, se, 0, g);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

@@ -63,6 +63,7 @@ struct GramLaunch {
   double jitter;
   int64_t col0 = 0;     // x2 / out are the column slice starting at this global column (lower test, diagonal rule)
   int* zero_info = nullptr;  // device int cleared by the launch
+  hipEvent_t start_event = nullptr, stop_event = nullptr;   // the kernel's own dispatch timestamps (profiling)
 };
 int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& g);
 
@@ -83,6 +84,7 @@ struct GemmLaunch {
   // completion event attached to the kernel's own dispatch (hipExtLaunchKernelGGL stopEvent): no separate
   // barrier packet behind the kernel (tools/sync_cost: 3.7 -> 2.3 us to the next kernel of the stream)
   hipEvent_t stop_event = nullptr;
+  hipEvent_t start_event = nullptr;   // dispatch start time (profiling: the kernel's own timestamps, not record packets around it)
   // one-pass (32x32-tile) path: every workgroup that stores a tile publishes it (write-through stores, then one
   // agent-scope add to this counter) for a consumer that is already resident (potrf_diag's resident start)
   unsigned* signal = nullptr;
@@ -272,3 +274,6 @@ struct gpx_handle {
 // profiling helpers (api.hip)
 void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double bytes);
 void prof_end(gpx_handle* h, hipStream_t s);
+// bracket by the kernel's OWN dispatch timestamps (hipExtLaunchKernelGGL start/stop events) instead of record packets
+// around it: returns false (and null events) when the stage is not being profiled
+bool prof_pair(gpx_handle* h, int stage, double flops, double bytes, hipEvent_t* a, hipEvent_t* b);

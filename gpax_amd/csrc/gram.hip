@@ -157,8 +157,8 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   const bool vec2 = (L.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(L.out) & 15) == 0);
 #define GPX_GRAM_LAUNCH(KIND)                                                        \
   do {                                                                               \
-    if (vec2) hipLaunchKernelGGL((gram_kernel<KIND, true>), grid, dim3(256), 0, s, g);  \
-    else hipLaunchKernelGGL((gram_kernel<KIND, false>), grid, dim3(256), 0, s, g);      \
+    if (vec2) hipExtLaunchKernelGGL((gram_kernel<KIND, true>), grid, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);  \
+    else hipExtLaunchKernelGGL((gram_kernel<KIND, false>), grid, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);      \
   } while (0)
   switch (L.kind) {
     case GPX_RBF: GPX_GRAM_LAUNCH(GPX_RBF); break;

@@ -162,7 +162,9 @@ int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, double* var
 #define GPX_STAGE_FACTOR_TOTAL 6
 #define GPX_STAGE_LOOKAHEAD 7   /* near / far look-ahead column updates (small latency-path GEMMs) */
 #define GPX_N_STAGES 8
-/* mode 0 = off (default), 1 = bracket every launch of each stage with HIP events. */
+/* mode 0 = off (default), 1 = bracket every launch of each stage with HIP events, 2 = only the whole step,
+ * the gram build and the epilogue (3 pairs per step), 3 = only the launches of the two roofline kernels (bulk
+ * update, gram build): what bench.py uses, since brackets on the chain stream stretch what they measure. */
 int gpx_profile_mode(gpx_handle* h, int mode);
 int gpx_profile_reset(gpx_handle* h);
 /* diagnostic: CSV (stage,start_us,end_us) of the bracketed launches since the last reset/get */

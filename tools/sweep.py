@@ -4,8 +4,8 @@ per-stage roofline figures of the two kernels that carry a roofline (gram -> HBM
 
     python tools/sweep.py [--out profiles/r01_sweep.json] [--max-n 32768]
 
-Timing: W warm-up steps, then K steps between device synchronisations (value), then the same K steps with
-per-launch HIP events (stage figures).  Whole-step flops = N^3/3 (Cholesky) + N^2 (M+1) (border rows:
+Timing: W warm-up steps, then K steps between device synchronisations (value), then the same K steps with the
+bulk-update and gram launches timed by their own dispatch timestamps (profile mode 3).  Whole-step flops = N^3/3 (Cholesky) + N^2 (M+1) (border rows:
 k_cross and r ride through the panel solves and updates) -- the algorithmic count, not what the kernels issue.
 """
 import argparse
@@ -70,7 +70,7 @@ def run(core, name, kind, n, d, m, steps, warmup, structured=False):
     assert info == 0 and np.isfinite(logp), (name, info, logp)
 
     core.profile_reset()
-    core.profile_mode(1)
+    core.profile_mode(3)   # only the two roofline kernels, by their own dispatch timestamps
     for _ in range(steps):
         step()
     core.synchronize()
