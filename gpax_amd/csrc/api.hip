@@ -294,7 +294,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_PAIR_MIN"))) h->pair_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
-  if ((env = getenv("GPX_RESIDENT"))) h->resident = atoi(env) != 0;
+  if ((env = getenv("GPX_RESIDENT"))) h->resident = std::min(std::max(atoi(env), 0), 2);
   if ((env = getenv("GPX_WINDOW"))) h->window = atoi(env) >= 3 ? 3 : 2;
   *out = h;
   return GPX_OK;
@@ -363,7 +363,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "pair_min")) { h->pair_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
-  if (!strcmp(name, "resident")) { h->resident = value != 0; return GPX_OK; }
+  if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   if (!strcmp(name, "window")) { h->window = value >= 3 ? 3 : 2; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
@@ -553,7 +553,7 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
   if (!h->ev_fork) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_fork, fl));
   if (!h->ev_gram) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_gram, fl));
   if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
-  GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, (int64_t)std::max<size_t>(nblk, 64)));
+  GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, 2 * (int64_t)std::max<size_t>(nblk, 64)));
   GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, 2 * (int64_t)h->nb * h->nb));
   while (h->ev_far.size() < nblk) {
     hipEvent_t a, b;
@@ -714,10 +714,18 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   // tile counter that the A -= S S^T kernel of step k publishes (potrf.hip).  Behind a saturating bulk update a
   // freshly launched potrf_diag waits 20-30 us for a CU to drain (it needs all of its LDS): this removes that
   // wait from the first ~11 block columns and the launch gap from all of them.
-  const bool resident = h->resident != 0 && !h->in_capture && !h->prof_mode && nblk >= 3;
+  const bool resident = h->resident != 0 && !h->in_capture && h->prof_mode != 1 && nblk >= 3;
   hipStream_t P2 = resident ? h->s_main2 : P;
   const unsigned n_signal = (unsigned)((nb / 32) * (nb / 32 + 1) / 2);   // lower 32x32 tiles of a diagonal block
-  if (resident) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)nblk * sizeof(unsigned), P));
+  if (resident) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(2 * nblk) * sizeof(unsigned), P));
+  // resident == 2: every hand-over of the chain is in-kernel.  The diagonal blocks run on one stream, the two band
+  // kernels on the other; S = A W_k^T is launched while potrf_diag(k) still runs and sleeps on the flag that kernel
+  // raises after its last (write-through) store of W_k -- the ~11 us from potrf_diag's last instruction to the
+  // start of the next kernel of its stream (store drain, kernel-end release, completion signal, launch) shrink to
+  // a flag round trip.
+  const bool chain2 = resident && h->resident >= 2;
+  unsigned* flagsU = h->d_flags;            // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
+  unsigned* flagsW = h->d_flags + nblk;     // [k]: W_k published (S = A W_k^T of step k waits)
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
@@ -742,7 +750,10 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
 
   // ---- the chain (stream P) at step k: potrf, then the diagonal band
   auto chain = [&](int64_t k) -> int {
-    hipStream_t P = (resident && (k & 1)) ? P2 : h->s_main;   // this step's chain stream (shadows the outer P)
+    // resident == 1: consecutive steps alternate between the two chain streams; resident == 2: potrf_diag on
+    // s_main, the band kernels on P2 (these shadow the outer P)
+    hipStream_t P = chain2 ? h->s_main : ((resident && (k & 1)) ? P2 : h->s_main);
+    hipStream_t PB = chain2 ? P2 : P;   // stream of the two band kernels
     double* S = h->d_mini + (k & 1) * nb * nb;
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
     // ev_w[k] = completion of potrf_diag(k): attached to the kernel's own dispatch when possible (no barrier
@@ -752,7 +763,8 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
     GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
                               h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr,
-                              (resident && k >= 1) ? h->d_flags + (k - 1) : nullptr, n_signal));
+                              (resident && k >= 1) ? flagsU + (k - 1) : nullptr, n_signal,
+                              (chain2 && need_w && k + 1 < nblk) ? flagsW + k : nullptr));
     prof_end(h, P);
     if (!need_w) return GPX_OK;
     if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
@@ -760,7 +772,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     if (k + 1 >= nblk) return GPX_OK;
     if (k >= 1) {   // columns k, k+1 were brought up to date by Q at step k-1
       if (!await(far_rec[(size_t)(k - 1)])) return GPX_ERR_HIP;
-      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_far[(size_t)(k - 1)], 0));
     }
     GemmLaunch g;
     g.A = A + r0 * ld + c0; g.lda = ld;
@@ -768,18 +780,19 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     g.C = S; g.ldc = nb;
     g.M = nb; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
     g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-    prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
-    GPX_RET(launch_gemm_nt(h, P, g));
-    prof_end(h, P);
+    if (chain2) { g.wait_flag = flagsW + k; g.wait_count = 1; }   // W_k arrives in-kernel from potrf_diag(k)
+    prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
+    GPX_RET(launch_gemm_nt(h, PB, g));
+    prof_end(h, PB);
     GemmLaunch u;
     u.A = S; u.lda = nb; u.B = S; u.ldb = nb;
     u.C = A + r0 * ld + r0; u.ldc = ld;
     u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
     u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
-    if (resident) u.signal = h->d_flags + k;   // potrf_diag(k+1) is already resident and polls this counter
-    prof_begin(h, P, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
-    GPX_RET(launch_gemm_nt(h, P, u));
-    prof_end(h, P);
+    if (resident) u.signal = flagsU + k;   // potrf_diag(k+1) is already resident and polls this counter
+    prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
+    GPX_RET(launch_gemm_nt(h, PB, u));
+    prof_end(h, PB);
     return GPX_OK;
   };
 

@@ -35,6 +35,7 @@ struct GemmArgs {
   // ((m / cyc_nb) * cyc_P + cyc_r) * cyc_nb + m % cyc_nb;  cyc_P <= 1: rows are global already
   int cyc_P, cyc_r, cyc_nb;
   unsigned* signal;   // one-pass path: publish the stored tile to an already-resident consumer (see GemmLaunch::signal)
+  const unsigned* wait_flag; unsigned wait_count;   // one-pass path: resident start (see GemmLaunch::wait_flag)
 };
 
 // first global row of the tile whose first (local) row is row_off + m0
@@ -403,8 +404,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
-  GEMM_TL(3, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));
   if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
+  if (g.wait_flag) {   // resident start: one lane polls (bounded: 2 s), one agent-scope acquire, the barrier releases the loads
+    if (tid == 0) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (__hip_atomic_load(g.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
+        __builtin_amdgcn_s_sleep(4);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+  }
+  GEMM_TL(3, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));
   const double* Ag = g.A + m0 * g.lda;
   const double* Bg = g.B + n0 * g.ldb;
   v2d ra[2][NCH], rb[2][NCH];
@@ -487,8 +500,8 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   g.a_upper_tri = L.a_upper_tri;
   g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
-  g.signal = L.signal;
-  if (L.signal && !(L.small_tile && (L.K == 128 || L.K == 64))) {
+  g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count;
+  if ((L.signal || L.wait_flag) && !(L.small_tile && (L.K == 128 || L.K == 64))) {
     gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel only");
     return GPX_ERR_ARG;
   }

@@ -88,13 +88,16 @@ struct GemmLaunch {
   // one-pass (32x32-tile) path: every workgroup that stores a tile publishes it (write-through stores, then one
   // agent-scope add to this counter) for a consumer that is already resident (potrf_diag's resident start)
   unsigned* signal = nullptr;
+  // one-pass path: the kernel is launched early and sleeps until *wait_flag >= wait_count (a producer that is
+  // still running publishes its output with write-through stores and then raises the flag)
+  const unsigned* wait_flag = nullptr; unsigned wait_count = 0;
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
 
 // Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda,
                       double* L, int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event = nullptr,
-                      const unsigned* wait_flag = nullptr, unsigned wait_count = 0);
+                      const unsigned* wait_flag = nullptr, unsigned wait_count = 0, unsigned* done_flag = nullptr);
 
 // y[0:ncols) = beta*y + alpha * x[0:nrows)^T A[0:nrows, 0:ncols)
 int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, int nrows, int64_t ncols,
@@ -185,7 +188,8 @@ struct gpx_handle {
   hipStream_t s_main2 = nullptr;   // second chain stream: consecutive diagonal blocks alternate, so the next potrf_diag can already be resident
   unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per-step tile counters of the resident start
   hipEvent_t ev_chain2 = nullptr;
-  int resident = 0;                // 1: resident start of potrf_diag in the split-panel schedule (measured: no gain, the early steps wait for the bulk update, not for a CU)
+  int resident = 2;                // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
+                                   // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag)
   std::string err;
   hipDeviceProp_t prop;
 

@@ -373,8 +373,14 @@ __device__ __forceinline__ void leaf_winv(double* Wd, double* share, int lane, i
 
 // one wave writes LDS tile (ib, jb) of `tiles` to the global matrix `dst` (leading dimension ld);
 // for a diagonal tile of L the don't-care entries above the diagonal become zeros
+// W_k is published with plain stores and ONE agent-scope release per wave in front of the flag (GPX_W_THROUGH 0):
+// write-through stores of every W tile (GPX_W_THROUGH 1) lengthened the kernel from 29 to 36 us.
+#ifndef GPX_W_THROUGH
+#define GPX_W_THROUGH 0
+#endif
+// `through`: write-through (agent-scope) stores, for a block that is handed to an already-resident consumer
 __device__ __forceinline__ void store_tile(const double* tiles, double* dst, int64_t ld, int ib, int jb, int lane,
-                                           bool zero_upper_of_diag) {
+                                           bool zero_upper_of_diag, bool through = false) {
   const int r = lane >> 2, c4 = (lane & 3) * 4;
   const double* src = tiles + tix(ib, jb) * 256;
   double* out = dst + (int64_t)(ib * 16 + r) * ld + jb * 16 + c4;
@@ -383,6 +389,11 @@ __device__ __forceinline__ void store_tile(const double* tiles, double* dst, int
   for (int q = 0; q < 4; ++q) {
     v[q] = src[eix(r, c4 + q)];
     if (zero_upper_of_diag && ib == jb && c4 + q > r) v[q] = 0.0;
+  }
+  if (through) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) __hip_atomic_store(&out[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
 #pragma unroll
   for (int q = 0; q < 4; ++q) out[q] = v[q];
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A
                                                                  int64_t lda, double* __restrict__ L,
                                                                  int64_t ldl, double* __restrict__ W,
                                                                  int* info, int col0, const unsigned* wait_flag,
-                                                                 unsigned wait_count) {
+                                                                 unsigned wait_count, unsigned* done_flag) {
   constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
   __shared__ double sm[2 * NTRI * 256 + LEAF_SHARE_DOUBLES];
   double* Lt = sm;
@@ -494,7 +505,10 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A
           double* ldst = L + (int64_t)(ib * 16 + r) * ldl + jb * 16 + c4;
           double* wdst = W + (int64_t)(ib * 16 + r) * NB + jb * 16 + c4;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) { ldst[q] = 0.0; wdst[q] = 0.0; }
+          for (int q = 0; q < 4; ++q) {
+            ldst[q] = 0.0;
+            wdst[q] = 0.0;
+          }
         }
       }
     }
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A
         // write out what is final: column jb of L (after phase A) and row jb-1 of W (previous slot)
         for (int q = wave - 2; q < NT; q += NWAVES - 2) {
           if (q < NT - jb) store_tile(Lt, L, ldl, jb + q, jb, lane, true);
-          else if (jb >= 1) store_tile(Wt, W, NB, jb - 1, q - (NT - jb), lane, false);
+          else if (jb >= 1) store_tile(Wt, W, NB, jb - 1, q - (NT - jb), lane, false, GPX_W_THROUGH && done_flag != nullptr);
         }
       }
     } else {
@@ -561,23 +575,34 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A
   {
     for (int q = wave; q < 2 * NT; q += NWAVES) {
       if (q == 0) store_tile(Lt, L, ldl, NT - 1, NT - 1, lane, true);
-      else if (q <= NT) store_tile(Wt, W, NB, NT - 1, q - 1, lane, false);
-      else if (NT >= 2) store_tile(Wt, W, NB, NT - 2, q - NT - 1, lane, false);
+      else if (q <= NT) store_tile(Wt, W, NB, NT - 1, q - 1, lane, false, GPX_W_THROUGH && done_flag != nullptr);
+      else if (NT >= 2) store_tile(Wt, W, NB, NT - 2, q - NT - 1, lane, false, GPX_W_THROUGH && done_flag != nullptr);
     }
   }
   GPX_STAMP(3 + 2 * NT);
   POTRF_TL(2, col0);
+  // publish W_k to the already-resident S = A W_k^T kernel: every wave drains its (write-through) stores, the
+  // barrier collects the waves, one lane raises the flag
+  if (done_flag) {
+#if GPX_W_THROUGH
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plain stores above: write this XCD's dirty lines back
+#endif
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(done_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda, double* L,
                       int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event, const unsigned* wait_flag,
-                      unsigned wait_count) {
+                      unsigned wait_count, unsigned* done_flag) {
   switch (nb) {
     case 64:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag);
       break;
     case 128:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), dim3(1), dim3(512), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), dim3(1), dim3(512), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

@@ -245,11 +245,11 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min, window)
     assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
 
 
-@pytest.mark.parametrize("option,value", [("resident", 1), ("host_threads", 2)])
+@pytest.mark.parametrize("option,value", [("resident", 0), ("resident", 1), ("host_threads", 2)])
 def test_optional_schedule_features_match_the_default(core, option, value):
-    """Two optional features of the split-panel schedule, off by default because they measured no gain: the
-    resident start of potrf_diag (in-kernel hand-off from the A -= S S^T tiles through write-through stores and
-    an agent-scope counter) and the second enqueueing host thread.  Same bits as the default schedule."""
+    """The in-kernel hand-overs of the chain (default resident = 2: potrf_diag and S = A W_k^T start resident and
+    sleep on flags raised by their producers) against kernel-boundary hand-overs (0) and the half-way mode (1),
+    and the optional second enqueueing host thread: same bits as the default schedule."""
     import gpax_amd
     from oracle import gp_oracle as orc
 
@@ -265,7 +265,7 @@ def test_optional_schedule_features_match_the_default(core, option, value):
         info1, logp1, mean1, var1 = core.fit_predict(prm, y - 1.0, np.ones(90), 0.0)
         assert info0 == 0 and info1 == 0
         assert np.array_equal(l0, l1) and logp0 == logp1 and np.array_equal(mean0, mean1) and np.array_equal(var0, var1)
-    core.set_option(option, 0 if option == "resident" else 1)
+    core.set_option(option, 2 if option == "resident" else 1)
     logp_ref, mean_ref, var_ref = orc.fit_predict(orc.RBF, x, y, xn, p)
     assert abs(logp1 - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
 
