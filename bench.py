@@ -119,8 +119,8 @@ def bench_distributed(args, rank, local_rank, world, dist, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--m", type=int, default=1000)

@@ -726,6 +726,9 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   const bool chain2 = resident && h->resident >= 2;
   unsigned* flagsU = h->d_flags;            // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
   unsigned* flagsW = h->d_flags + nblk;     // [k]: W_k published (S = A W_k^T of step k waits)
+  static int q_res_env = -1;
+  if (q_res_env < 0) { const char* e = getenv("GPX_Q_RESIDENT_WGS"); q_res_env = e ? atoi(e) : 0; }
+  const int64_t q_resident_wgs = q_res_env;
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
@@ -812,9 +815,14 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     const int64_t mrows = rows - r0;
     if (mrows <= 0) return GPX_OK;
     if (!await(w_rec[(size_t)k])) return GPX_ERR_HIP;
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
+    // resident == 2 and a panel of at most `q_resident_wgs` workgroups: the panel kernel starts resident too and
+    // sleeps on potrf_diag's flag (a cross-stream event costs ~8 us from the producer's end to the consumer's
+    // start, tools/sync_cost); wider panels keep the event so that sleeping workgroups do not crowd the bulk update
+    const bool q_resident = chain2 && k + 1 < nblk && (mrows / 32) * (nb / 32) <= q_resident_wgs;
+    if (!q_resident) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
     {
       GemmLaunch g;
+      if (q_resident) { g.wait_flag = flagsW + k; g.wait_count = 1; }
       g.A = A + r0 * ld + c0; g.lda = ld;
       g.B = h->d_W + k * nb * nb; g.ldb = nb;
       g.C = L + r0 * ld + c0; g.ldc = ld;
