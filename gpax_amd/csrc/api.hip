@@ -294,6 +294,9 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_PAIR_MIN"))) h->pair_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
+  // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
+  // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
+  if (getenv("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS")) h->resident = 0;
   if ((env = getenv("GPX_RESIDENT"))) h->resident = std::min(std::max(atoi(env), 0), 2);
   if ((env = getenv("GPX_WINDOW"))) h->window = atoi(env) >= 3 ? 3 : 2;
   *out = h;
@@ -783,7 +786,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     g.C = S; g.ldc = nb;
     g.M = nb; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
     g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-    if (chain2) { g.wait_flag = flagsW + k; g.wait_count = 1; }   // W_k arrives in-kernel from potrf_diag(k)
+    if (chain2) { g.wait_flag = flagsW + k; g.wait_count = 1; g.wait_info = h->d_info; }   // W_k arrives in-kernel from potrf_diag(k)
     prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
     GPX_RET(launch_gemm_nt(h, PB, g));
     prof_end(h, PB);
@@ -822,7 +825,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     if (!q_resident) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
     {
       GemmLaunch g;
-      if (q_resident) { g.wait_flag = flagsW + k; g.wait_count = 1; }
+      if (q_resident) { g.wait_flag = flagsW + k; g.wait_count = 1; g.wait_info = h->d_info; }
       g.A = A + r0 * ld + c0; g.lda = ld;
       g.B = h->d_W + k * nb * nb; g.ldb = nb;
       g.C = L + r0 * ld + c0; g.ldc = ld;
@@ -1102,11 +1105,23 @@ static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_ro
   return GPX_OK;
 }
 
+// info == -7: a resident kernel gave up waiting for its producer (potrf.hip / gemm.hip: bounded spin).  That only
+// happens when something serialises the dispatches (a profiler collecting counters, a debugger): switch the handle
+// to kernel-boundary hand-overs and tell the caller to repeat the call.
+static int check_handover(gpx_handle* h, int info) {
+  if (info != -7) return GPX_OK;
+  h->resident = 0;
+  h->have_factor = false; h->have_z = false;
+  gpx_set_error(h, "in-kernel hand-over timed out (are kernel dispatches being serialised, e.g. by counter collection?); "
+                   "switched to kernel-boundary hand-overs (option \"resident\" = 0): repeat the call");
+  return GPX_ERR_STATE;
+}
+
 static int read_info(gpx_handle* h, int* info) {
   const double* blk;
   GPX_RET(fetch_block(h, 0, &blk));
   *info = reinterpret_cast<const int*>(blk + 8)[0];
-  return GPX_OK;
+  return check_handover(h, *info);
 }
 
 extern "C" int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double* K_out, double* L_out) {
@@ -1393,6 +1408,7 @@ extern "C" int gpx_posterior(gpx_handle* h, const double* m_new, double new_nois
   }
   const double* blk;   // [scal | info | mean(m) | var(m)] in one copy
   GPX_RET(fetch_block(h, 2 * m, &blk));
+  GPX_RET(check_handover(h, reinterpret_cast<const int*>(blk + 8)[0]));
   if (mean_out) memcpy(mean_out, blk + GPX_OUT_HEAD, (size_t)m * sizeof(double));
   if (var_out) memcpy(var_out, blk + GPX_OUT_HEAD + m, (size_t)m * sizeof(double));
   return reinterpret_cast<const int*>(blk + 8)[0];
@@ -1565,6 +1581,7 @@ extern "C" int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, 
   GPX_RET(fetch_block(h, m > 0 ? 2 * m : 0, &blk));
   const double scal[2] = {blk[0], blk[1]};
   const int info = reinterpret_cast<const int*>(blk + 8)[0];
+  GPX_RET(check_handover(h, info));
   if (mean_out && m > 0) memcpy(mean_out, blk + GPX_OUT_HEAD, (size_t)m * sizeof(double));
   if (var_out && m > 0) memcpy(var_out, blk + GPX_OUT_HEAD + m, (size_t)m * sizeof(double));
   if (logp) *logp = -0.5 * scal[1] - scal[0] - 0.5 * (double)h->n * log(2.0 * M_PI);

@@ -36,6 +36,7 @@ struct GemmArgs {
   int cyc_P, cyc_r, cyc_nb;
   unsigned* signal;   // one-pass path: publish the stored tile to an already-resident consumer (see GemmLaunch::signal)
   const unsigned* wait_flag; unsigned wait_count;   // one-pass path: resident start (see GemmLaunch::wait_flag)
+  int* wait_info;     // set to -7 when the bounded wait gives up
 };
 
 // first global row of the tile whose first (local) row is row_off + m0
@@ -405,12 +406,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
   if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
-  if (g.wait_flag) {   // resident start: one lane polls (bounded: 2 s), one agent-scope acquire, the barrier releases the loads
+  if (g.wait_flag) {   // resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
     if (tid == 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (__hip_atomic_load(g.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
         __builtin_amdgcn_s_sleep(4);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) break;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) { if (g.wait_info) atomicMin(g.wait_info, -7); break; }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -500,7 +501,7 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   g.a_upper_tri = L.a_upper_tri;
   g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
-  g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count;
+  g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
   if ((L.signal || L.wait_flag) && !(L.small_tile && (L.K == 128 || L.K == 64))) {
     gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel only");
     return GPX_ERR_ARG;

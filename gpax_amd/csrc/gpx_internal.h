@@ -91,6 +91,7 @@ struct GemmLaunch {
   // one-pass path: the kernel is launched early and sleeps until *wait_flag >= wait_count (a producer that is
   // still running publishes its output with write-through stores and then raises the flag)
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;
+  int* wait_info = nullptr;   // device int set to -7 if the bounded wait gives up
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
 

@@ -439,14 +439,14 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A
   // CU to drain), and sleeps here until the `wait_count` workgroups of the preceding A_kk -= S S^T kernel have
   // published their tiles (write-through stores + an agent-scope counter, gemm.hip).  One lane polls, relaxed;
   // ONE agent-scope acquire after the match drops this CU's stale lines; then the barrier releases the loads.
-  // The spin is bounded (2 s of s_memrealtime): on a timeout the block reports info = -7 and carries on.
+  // The spin is bounded (0.25 s of s_memrealtime): on a timeout the block reports info = -7 and carries on.
   if (wait_flag) {
     POTRF_TL(5, col0);
     if (tid == 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_count) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { atomicMin(info, -7); break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) { atomicMin(info, -7); break; }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
