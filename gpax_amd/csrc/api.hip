@@ -298,7 +298,6 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
   if (getenv("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS")) h->resident = 0;
   if ((env = getenv("GPX_RESIDENT"))) h->resident = std::min(std::max(atoi(env), 0), 2);
-  if ((env = getenv("GPX_WINDOW"))) h->window = atoi(env) >= 3 ? 3 : 2;
   *out = h;
   return GPX_OK;
 }
@@ -319,8 +318,6 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
-  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
-  if (h->ev_gram) (void)hipEventDestroy(h->ev_gram);
   for (auto e : h->ev_far) (void)hipEventDestroy(e);
   for (auto e : h->ev_w) (void)hipEventDestroy(e);
   for (auto e : h->ev_panel) (void)hipEventDestroy(e);
@@ -367,7 +364,6 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
-  if (!strcmp(name, "window")) { h->window = value >= 3 ? 3 : 2; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -382,7 +378,6 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
-  if (!strcmp(name, "window")) { *value = h->window; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
   return GPX_ERR_ARG;
 }
@@ -553,8 +548,6 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
   const unsigned fl = sync_event_flags();
   if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, fl));
   if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
-  if (!h->ev_fork) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_fork, fl));
-  if (!h->ev_gram) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_gram, fl));
   if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
   GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, 2 * (int64_t)std::max<size_t>(nblk, 64)));
   GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, 2 * (int64_t)h->nb * h->nb));
@@ -729,9 +722,6 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   const bool chain2 = resident && h->resident >= 2;
   unsigned* flagsU = h->d_flags;            // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
   unsigned* flagsW = h->d_flags + nblk;     // [k]: W_k published (S = A W_k^T of step k waits)
-  static int q_res_env = -1;
-  if (q_res_env < 0) { const char* e = getenv("GPX_Q_RESIDENT_WGS"); q_res_env = e ? atoi(e) : 0; }
-  const int64_t q_resident_wgs = q_res_env;
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
@@ -818,14 +808,11 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     const int64_t mrows = rows - r0;
     if (mrows <= 0) return GPX_OK;
     if (!await(w_rec[(size_t)k])) return GPX_ERR_HIP;
-    // resident == 2 and a panel of at most `q_resident_wgs` workgroups: the panel kernel starts resident too and
-    // sleeps on potrf_diag's flag (a cross-stream event costs ~8 us from the producer's end to the consumer's
-    // start, tools/sync_cost); wider panels keep the event so that sleeping workgroups do not crowd the bulk update
-    const bool q_resident = chain2 && k + 1 < nblk && (mrows / 32) * (nb / 32) <= q_resident_wgs;
-    if (!q_resident) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
+    // (Starting the panel kernel resident too -- it would sleep on potrf_diag's flag instead of waiting ~8 us for the
+    // cross-stream event -- crowds the bulk update with sleeping workgroups: 1.76 -> 1.81 ms, not used.)
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
     {
       GemmLaunch g;
-      if (q_resident) { g.wait_flag = flagsW + k; g.wait_count = 1; g.wait_info = h->d_info; }
       g.A = A + r0 * ld + c0; g.lda = ld;
       g.B = h->d_W + k * nb * nb; g.ldb = nb;
       g.C = L + r0 * ld + c0; g.ldc = ld;
@@ -833,7 +820,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
       // T gets its own event on the panel: the bulk update must not wait for the column kernels below (with one
       // shared event after them the N = 4096 step went from 1.90 to 2.17 ms: every bulk update starts late)
-      const bool t_needs = k + 1 < nblk && k == group_end && nblk - (k + 1 + (h->window >= 3 ? 3 : 2)) > 0;
+      const bool t_needs = k + 1 < nblk && k == group_end && nblk - (k + 3) > 0;
       if (t_needs && attach) g.stop_event = h->ev_panel[(size_t)k];
       prof_begin(h, Q, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
       GPX_RET(launch_gemm_nt(h, Q, g));
@@ -842,82 +829,51 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     }
     if (k + 1 >= nblk) return GPX_OK;   // border rows only: nothing left to update
 
-    // Q's window of `w` columns.  w = 2: columns k+1 (panel k) and k+2 (every panel since T's last step).
-    // w = 3: columns k+1, k+2 (panel k; both were in the window at step k-1) -> ev_far, THEN column k+3 enters
-    // the window with every panel since T's last step.  With w = 3 nothing P waits for depends on T any more
-    // (P(k+1) <- Q(k) first kernel <- Q(k-1) second kernel <- T), which gives T one more step of slack: enough to
-    // group the bulk updates in the bulk-bound first steps of a small matrix too.
-    const int w = h->window >= 3 ? 3 : 2;
+    // Q keeps two columns current ahead of the chain: column k+1 (below its diagonal block) gets panel k, column
+    // k+2 every panel since T's last step; rows from block row k+2 down.  (A third window column, which takes T
+    // off everything P waits for, was tried with and without grouped updates: 1.94-2.02 vs 1.88 ms at N = 4096.)
     const int64_t rr = (k + 2) * nb, mr = rows - rr;
     bool far_attached = false;
-    auto wait_gram = [&]() -> int {
-      if (h->gram_pending) {   // columns >= 3 were built on T (split gram build)
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_gram, 0));
-        h->gram_pending = false;
-      }
-      return GPX_OK;
-    };
-    auto wait_bulk = [&]() -> int {   // the column entering the window was last written by T's step last_t
-      if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
-        q_waited_t = last_t;
-      }
-      return GPX_OK;
-    };
-    auto col_update = [&](int64_t r_first, int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last) -> int {
-      GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= r_first, -= panels [kfirst, kfirst+npan)
-      const int64_t mrr = rows - r_first;
+    auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last) -> int {
+      GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= rr, -= panels [kfirst, kfirst+npan)
       if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
-      t.A = L + r_first * ld + kfirst * nb; t.lda = ld;
+      t.A = L + rr * ld + kfirst * nb; t.lda = ld;
       t.B = L + cfirst * nb * ld + kfirst * nb; t.ldb = ld;
-      t.C = A + r_first * ld + cfirst * nb; t.ldc = ld;
-      t.M = mrr; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-      t.lower = 1; t.row_off = r_first; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 1;
+      t.C = A + rr * ld + cfirst * nb; t.ldc = ld;
+      t.M = mr; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
+      t.lower = 1; t.row_off = rr; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 1;
       double entries = 0.0;
       for (int64_t c = cfirst; c < cfirst + ncol; ++c)
-        entries += (c * nb >= r_first) ? (double)nb * (nb + 1) / 2.0 + (double)(mrr - nb) * nb : (double)mrr * nb;
-      prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(mrr + ncol * nb) * t.K));
+        entries += (c * nb >= rr) ? (double)nb * (nb + 1) / 2.0 + (double)(mr - nb) * nb : (double)mr * nb;
+      prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(mr + ncol * nb) * t.K));
       int rc = launch_gemm_nt(h, Q, t);
       prof_end(h, Q);
       return rc;
     };
     const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
-    if (w == 2) {
-      if (mr > 0) {
-        if (k >= 1) GPX_RET(wait_gram());
-        GPX_RET(wait_bulk());
-        const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
-        if (npan2 > 1 && ncb > 1) {
-          GPX_RET(col_update(rr, k + 1, 1, k, 1, false));
-          GPX_RET(col_update(rr, k + 2, 1, last_t + 1, npan2, true));
-        } else {
-          GPX_RET(col_update(rr, k + 1, ncb, k, 1, true));
-        }
+    if (mr > 0) {
+      if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {   // column k+2 was last written by T there
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
+        q_waited_t = last_t;
       }
-      if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
-      far_rec[(size_t)k].store(1, std::memory_order_release);
-    } else {
-      if (mr > 0) {
-        if (k >= 1) GPX_RET(wait_gram());
-        GPX_RET(col_update(rr, k + 1, ncb, k, 1, true));
-      }
-      if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
-      far_rec[(size_t)k].store(1, std::memory_order_release);
-      const int64_t r3 = (k + 3) * nb;
-      if (k + 3 < nblk && rows - r3 > 0) {
-        GPX_RET(wait_gram());
-        GPX_RET(wait_bulk());
-        GPX_RET(col_update(r3, k + 3, 1, last_t + 1, k - last_t, false));
+      const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
+      if (npan2 > 1 && ncb > 1) {
+        GPX_RET(col_update(k + 1, 1, k, 1, false));
+        GPX_RET(col_update(k + 2, 1, last_t + 1, npan2, true));
+      } else {
+        GPX_RET(col_update(k + 1, ncb, k, 1, true));
       }
     }
+    if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
+    far_rec[(size_t)k].store(1, std::memory_order_release);
 
-    // T: bulk, columns >= k+1+w, panels last_t+1 .. k in one pass
-    const int64_t nbulk = nblk - (k + 1 + w);
+    // T: bulk, columns >= k+3, panels last_t+1 .. k in one pass
+    const int64_t nbulk = nblk - (k + 3);
     if (k == group_end) {
       if (nbulk > 0) {
         GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
         const int64_t kfirst = last_t + 1, npan = k - last_t;
-        const int64_t cf = k + 1 + w, br = cf * nb, bm = rows - br, nc = nbulk * nb;
+        const int64_t cf = k + 3, br = cf * nb, bm = rows - br, nc = nbulk * nb;
         GemmLaunch t;
         t.A = L + br * ld + kfirst * nb; t.lda = ld;
         t.B = L + br * ld + kfirst * nb; t.ldb = ld;
@@ -1030,53 +986,21 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     prof_end(h, st);
     return rc;
   };
-  const int64_t csplit = 3 * h->nb;
-  static int split_env = -1;
-  if (split_env < 0) { const char* e = getenv("GPX_GRAM_SPLIT"); split_env = e ? atoi(e) : 0; }
-  const bool split = split_env != 0 && h->lookahead != 0 && h->depth >= 3 && !fp.want_k && n > csplit;
-  h->gram_pending = false;
   double fl, by;
-  if (!split) {
-    g.zero_info = h->d_info;
-    gram_cost(0, n, &fl, &by);
-    (void)prof_pair(h, GPX_STAGE_GRAM, fl, by, &g.start_event, &g.stop_event);
-    GPX_RET(launch_gram(h, s, g));
-    if (K_out) {
-      GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
-                                        (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
-    }
-    GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
-    GPX_RET(cross_gram(s));
-    // the r row and the unused (zero) border rows in one launch
-    GPX_RET(launch_border_rows(h, s, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
-  } else {
-    // Split build for the split-panel schedule (GPX_GRAM_SPLIT=1; off by default): the chain stream builds only
-    // the three block columns the first steps need and starts factorising; the rest of K is built on the bulk
-    // stream (in front of its first update), k_cross and the border rows on the panel stream.  Measured: no gain
-    // at N = 4096 (1.907 vs 1.905 ms) -- the first steps are bound by the bulk stream, which now also carries
-    // most of the gram build -- so the plain sequence stays the default.
-    hipStream_t Q = h->s_far, T = h->s_trail;
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_fork, s));          // hyper-parameters are uploaded, the last step has joined
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_fork, 0));
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_fork, 0));
-    GramLaunch g1 = g;
-    g1.n2 = csplit; g1.col0 = 0; g1.zero_info = h->d_info;
-    gram_cost(0, csplit, &fl, &by);
-    prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
-    GPX_RET(launch_gram(h, s, g1));
-    prof_end(h, s);
-    GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
-    GramLaunch g2 = g;
-    g2.x2 = h->d_x + csplit * d; g2.n2 = n - csplit; g2.col0 = csplit; g2.out = h->d_A + csplit;
-    gram_cost(csplit, n, &fl, &by);
-    prof_begin(h, T, GPX_STAGE_GRAM, fl, by);
-    GPX_RET(launch_gram(h, T, g2));
-    prof_end(h, T);
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_gram, T));
-    h->gram_pending = true;
-    GPX_RET(cross_gram(Q));
-    GPX_RET(launch_border_rows(h, Q, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
+  g.zero_info = h->d_info;
+  gram_cost(0, n, &fl, &by);
+  (void)prof_pair(h, GPX_STAGE_GRAM, fl, by, &g.start_event, &g.stop_event);
+  GPX_RET(launch_gram(h, s, g));
+  if (K_out) {
+    GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
+                                      (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
   }
+  GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
+  GPX_RET(cross_gram(s));
+  // the r row and the unused (zero) border rows in one launch.  (Building most of K on the bulk stream while the
+  // chain already factorises was tried: no gain at N = 4096, 1.907 vs 1.905 ms -- the first steps are bound by
+  // that stream.)
+  GPX_RET(launch_border_rows(h, s, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
 
   GPX_RET(factor_loop(h, rows));
 
@@ -1520,7 +1444,7 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
     // d_hyp / d_noise / d_r / d_mnew, so the same graph is replayed for every hyper-parameter draw.
     char key[512];
     snprintf(key, sizeof(key), "%d|%d|%lld|%lld|%d|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p", fp.kind, fp.apply_noise,
-             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth + 16 * h->pair_min + 4096 * h->quad_min + 1000000 * h->window, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
+             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth + 16 * h->pair_min + 4096 * h->quad_min, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
              (void*)h->d_x, (void*)h->d_xnew, (void*)h->d_r, (void*)(h->have_mnew ? h->d_mnew : nullptr),
              (void*)h->d_hyp, (void*)fp.noise_dev, (void*)h->d_mean, (void*)h->d_z);
     auto it = h->graphs.find(key);

@@ -199,7 +199,6 @@ struct gpx_handle {
   int lookahead = 1;
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 32;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
-  int window = 2;      // split-panel schedule: block columns the panel stream keeps current ahead of the chain (2 | 3)
   int quad_min = 48;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
@@ -263,7 +262,6 @@ struct gpx_handle {
   std::vector<hipEvent_t> ev_panel, ev_trail;
   hipEvent_t ev_join = nullptr, ev_join2 = nullptr;
   std::vector<hipEvent_t> ev_far, ev_w;
-  hipEvent_t ev_fork = nullptr, ev_gram = nullptr; bool gram_pending = false;   // split gram build (depth 3)
   double* d_mini = nullptr; int64_t mini_cap = 0;   // nb x nb scratch of the split-panel schedule (L_{k+1,k} for the chain)
 
   DistState dist;

@@ -20,7 +20,6 @@ TOL_K = 1e-12
 TOL_L = 1e-10
 TOL_LOGP_REL = 1e-10
 TOL_POST = 1e-8
-DEFAULT_WINDOW = 2
 
 
 @pytest.fixture(scope="module")
@@ -214,9 +213,8 @@ def test_lookahead_schedules_are_deterministic(core, depth):
     assert np.abs(l0 - orc.cholesky_lower(orc.rbf(x, x, 1.0, 1.0, p["k_noise"], 1e-6))).max() <= TOL_L
 
 
-@pytest.mark.parametrize("window", [2, 3])
 @pytest.mark.parametrize("pair_min,quad_min", [(0, 0), (1, 0), (6, 0), (13, 0), (1, 1), (4, 10), (0, 7)])
-def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min, window):
+def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
     """The split-panel schedule groups the bulk updates (the last 2 or 4 panels in one K = 2 nb / 4 nb pass)
     while more than pair_min / quad_min block columns remain: never grouped, always paired, always in fours and
     several switch points all give the same factor, posterior and log-marginal."""
@@ -228,7 +226,6 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min, window)
     core.set_option("nb", 64)
     core.set_option("pair_min", pair_min)
     core.set_option("quad_min", quad_min)
-    core.set_option("window", window)
     core.set_train(x)
     core.set_test(xn)
     _, _, l = core.fit_factor(prm, want_l=True)
@@ -236,7 +233,6 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min, window)
     core.set_option("nb", 128)
     core.set_option("pair_min", 32)
     core.set_option("quad_min", 48)
-    core.set_option("window", DEFAULT_WINDOW)
     assert info == 0
     k_ref = orc.rbf(x, x, p["k_scale"], p["k_length"], p["k_noise"], p["k_jitter"])
     assert np.abs(l - orc.cholesky_lower(k_ref)).max() <= TOL_L
