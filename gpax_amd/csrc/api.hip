@@ -516,16 +516,22 @@ extern "C" int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const dou
   if (h->n <= 0) { gpx_set_error(h, "gpx_set_targets: call gpx_set_train first"); return GPX_ERR_STATE; }
   if (!y_minus_m) { gpx_set_error(h, "gpx_set_targets: y_minus_m is NULL"); return GPX_ERR_ARG; }
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  // through the pinned ring (asynchronous; the caller's arrays are free again on return) unless they are large
+  auto up = [&](double* dst, const double* src, int64_t cnt) -> int {
+    if (cnt <= 65536) return upload_small(h, h->s_main, dst, src, cnt);
+    GPX_HIP_CHECK(h, hipMemcpyAsync(dst, src, (size_t)cnt * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+    GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+    return GPX_OK;
+  };
   GPX_RET(ensure(h, &h->d_r, &h->r_cap, h->n));
-  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+  GPX_RET(up(h->d_r, y_minus_m, h->n));
   h->have_r = true;
   h->have_mnew = false;
   if (m_new && h->m > 0) {
     GPX_RET(ensure(h, &h->d_mnew, &h->mnew_cap, h->m));
-    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_mnew, m_new, (size_t)h->m * sizeof(double), hipMemcpyHostToDevice, h->s_main));
+    GPX_RET(up(h->d_mnew, m_new, h->m));
     h->have_mnew = true;
   }
-  GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
   return GPX_OK;
 }
 
@@ -726,6 +732,10 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
   if (resident) GPX_HIP_CHECK(h, hipStreamWaitEvent(P2, h->ev_join, 0));
+  // gradient path: K^-1 is accumulated on T while the chain runs (see kinv_update below); T is idle until the
+  // first panel is complete, so clearing the accumulator there costs nothing
+  const bool kinv = h->kinv_U != nullptr;
+  if (kinv) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_kinv, 0, (size_t)(h->kinv_rows * npad) * sizeof(double), T));
 
   // Host-side hand-shake between the two enqueueing threads: an event may only be waited for after the call
   // that records it has been ISSUED (a wait on a not-yet-recorded event is a no-op).
@@ -793,10 +803,16 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   };
 
   // ---- the side streams at step k: Q (whole panel, columns k+1 and k+2), T (bulk)
-  const int64_t pair_min = h->pair_min, quad_min = h->quad_min;
+  // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
+  // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
+  const int64_t pair_min = kinv ? std::min<int64_t>(h->pair_min, 8) : h->pair_min, quad_min = h->quad_min;
   int64_t last_t = -1;        // last step at which T acted (panels <= last_t are in every column >= last_t+3)
   int64_t group_end = -1;     // the step at which T acts next
   int64_t q_waited_t = -1;    // the T step Q has already waited for
+  int64_t kinv_last = -1;     // last panel folded into K^-1 (gradient path)
+  static int kinv_group_env = -1;
+  if (kinv_group_env < 0) { const char* e = getenv("GPX_KINV_GROUP"); kinv_group_env = e ? atoi(e) : 2; }
+  const int64_t kinv_group = std::max(kinv_group_env, 1);
   std::vector<char> t_pending((size_t)nblk, 0);
   auto side = [&](int64_t k) -> int {
     if (k > group_end) {
@@ -820,14 +836,40 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
       // T gets its own event on the panel: the bulk update must not wait for the column kernels below (with one
       // shared event after them the N = 4096 step went from 1.90 to 2.17 ms: every bulk update starts late)
-      const bool t_needs = k + 1 < nblk && k == group_end && nblk - (k + 3) > 0;
+      const bool t_needs = (k + 1 < nblk && k == group_end && nblk - (k + 3) > 0) || (kinv && (k == group_end || k + 1 >= nblk));
       if (t_needs && attach) g.stop_event = h->ev_panel[(size_t)k];
       prof_begin(h, Q, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
       GPX_RET(launch_gemm_nt(h, Q, g));
       prof_end(h, Q);
       if (t_needs && !attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
     }
-    if (k + 1 >= nblk) return GPX_OK;   // border rows only: nothing left to update
+    // K^-1 += U_{:,j} U_{:,j}^T for the panels j = last_t+1 .. k that are complete now (gradient path): rank-(npan nb)
+    // update of the leading (k+1) nb square, lower tiles, on T.  Small while the bulk updates are big and growing as
+    // they shrink, it fills the chain-bound second half of the factorisation with the N^3/3 flops that used to
+    // follow it as one U U^T product (2.9 -> 2.2 ms per gradient call at N = 4096).
+    auto kinv_update = [&]() -> int {
+      const int64_t kfirst = kinv_last + 1, npan = k - kinv_last;
+      kinv_last = k;
+      const int64_t msq = std::min<int64_t>(h->kinv_rows, (k + 1) * nb);
+      GemmLaunch t;
+      t.A = h->kinv_U + kfirst * nb; t.lda = ld;
+      t.B = h->kinv_U + kfirst * nb; t.ldb = ld;
+      t.C = h->d_kinv; t.ldc = npad;
+      t.M = msq; t.N = msq; t.K = npan * nb; t.alpha = 1.0; t.beta = 1.0;
+      t.lower = 1; t.row_off = 0; t.col_off = 0; t.b_lower_tri = 0; t.small_tile = 0;
+      const double entries = (double)msq * (msq + 1) / 2.0;
+      prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + 2.0 * (double)msq * t.K));
+      int rc = launch_gemm_nt(h, T, t);
+      prof_end(h, T);
+      return rc;
+    };
+    if (k + 1 >= nblk) {   // border rows only: nothing left to update
+      if (kinv) {
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
+        GPX_RET(kinv_update());
+      }
+      return GPX_OK;
+    }
 
     // Q keeps two columns current ahead of the chain: column k+1 (below its diagonal block) gets panel k, column
     // k+2 every panel since T's last step; rows from block row k+2 down.  (A third window column, which takes T
@@ -888,6 +930,13 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         GPX_RET(launch_gemm_nt(h, T, t));
         if (!attach || timed) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
         t_pending[(size_t)k] = 1;
+      }
+      // behind the bulk update (Q's next column update waits for that one, not for this), two panels at a time:
+      // nothing waits for K^-1 before the end and K = 2 nb passes run at 48 instead of 40 TFLOP/s (groups of 4 or 8
+      // leave a long last pass exposed behind the chain: 2.58 / 2.68 / 2.85 ms per call at N = 4096)
+      if (kinv && (k - kinv_last >= kinv_group || k + 2 >= nblk)) {
+        if (nbulk <= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
+        GPX_RET(kinv_update());
       }
       last_t = k;
     }
@@ -1163,13 +1212,18 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   GPX_RET(ensure(h, &h->d_r, &h->r_cap, n));
   GPX_RET(ensure(h, &h->d_vec, &h->vec_cap, 2 * npad));
   GPX_RET(ensure(h, &h->d_kinv, &h->kinv_cap, n64 * npad));
-  GPX_RET(ensure_out(h, 2));
+  // the small results travel in ONE pinned copy: [scal | info | alpha (npad) | the reduction's sums]
+  const int per_dim = (p->n_length > 1 || (p->kind == GPX_PERIODIC && p->n_period > 1)) ? 1 : 0;
+  const int DCH = grad_chunk_dims(), NPVv = grad_partials_per_chunk();
+  const int nchunk = per_dim ? (d + DCH - 1) / DCH : 1;
+  GPX_RET(ensure_out(h, npad + (int64_t)nchunk * NPVv));
   GPX_RET(ensure_events(h, (size_t)(npad / nb)));
   h->npad = npad; h->epad = epad; h->ld = ld;
 
   const double* noise_dev; double noise_scalar;
   GPX_RET(upload_params(h, s, p, n, d, &noise_dev, &noise_scalar));
-  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+  if (n <= 65536) GPX_RET(upload_small(h, s, h->d_r, y_minus_m, n));   // through the pinned ring: truly asynchronous
+  else GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
   h->have_r = true;
 
   // ---- [K ; r ; I] in d_A
@@ -1195,10 +1249,16 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   GPX_HIP_CHECK(h, hipMemsetAsync(h->d_L + npad * ld, 0, (size_t)(epad * ld) * sizeof(double), s));
   GPX_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
 
-  GPX_RET(factor_loop(h, rows, npad + RZ));
-
   const double* zrow = h->d_L + npad * ld;
   const double* U = h->d_L + (npad + RZ) * ld;
+  // K^-1 = U U^T (lower 64x64 tiles) is accumulated panel by panel inside the split-panel schedule; the classic
+  // schedules (options "depth" 1|2, "lookahead" 0) form it in one product after the factorisation
+  const bool fused_kinv = h->lookahead != 0 && h->depth >= 3;
+  if (fused_kinv) { h->kinv_U = U; h->kinv_rows = n64; }
+  int frc = factor_loop(h, rows, npad + RZ);
+  h->kinv_U = nullptr; h->kinv_rows = 0;
+  GPX_RET(frc);
+
   EpilogueLaunch e;
   e.L = h->d_L; e.ld = ld; e.n = n; e.z = zrow; e.vt = nullptr; e.vt_ld = 0; e.m = 0; e.m_new = nullptr;
   e.prior_diag = 0.0; e.scal = h->d_scal; e.mean = nullptr; e.var = nullptr;
@@ -1206,10 +1266,11 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   GPX_RET(launch_epilogue(h, s, e));
 
   // ---- alpha = L^-T z = U z
-  double* alpha = h->d_vec + npad;
+  double* alpha = h->d_mean;   // inside the result block
   GPX_RET(launch_utri_gemv(h, s, U, ld, h->d_z, alpha, n, npad));
 
   // ---- K^-1 = U U^T, lower 64x64 tiles; U_ik = 0 for k < i, so each tile starts at its first row
+  if (!fused_kinv) {
   GemmLaunch u;
   u.A = U; u.lda = ld; u.B = U; u.ldb = ld; u.C = h->d_kinv; u.ldc = npad;
   u.M = n64; u.N = n64; u.K = npad; u.alpha = 1.0; u.beta = 0.0;
@@ -1220,24 +1281,23 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
     GPX_RET(launch_gemm_nt(h, s, u));
     prof_end(h, s);
   }
+  }
 
   // ---- the reduction
-  const int per_dim = (p->n_length > 1 || (p->kind == GPX_PERIODIC && p->n_period > 1)) ? 1 : 0;
-  const int DCH = grad_chunk_dims(), NPVv = grad_partials_per_chunk();
-  const int nchunk = per_dim ? (d + DCH - 1) / DCH : 1;
   const int64_t T = (n + 63) / 64, ntiles = T * (T + 1) / 2;
   const int nwg = (int)std::min<int64_t>(ntiles, 1024);
-  GPX_RET(ensure(h, &h->d_gpart, &h->gpart_cap, (int64_t)nchunk * (nwg + 1) * NPVv));
-  double* sums_dev = h->d_gpart + (int64_t)nchunk * nwg * NPVv;
+  GPX_RET(ensure(h, &h->d_gpart, &h->gpart_cap, (int64_t)nchunk * nwg * NPVv));
+  double* sums_dev = h->d_mean + npad;
   GPX_RET(launch_grad_reduce(h, s, p->kind, h->d_x, h->d_hyp, h->d_kinv, npad, alpha, n, d, per_dim, nwg, h->d_gpart,
                              sums_dev));
 
-  std::vector<double> sums((size_t)nchunk * NPVv);
-  double scal[2]; int info = 0;
-  GPX_HIP_CHECK(h, hipMemcpyAsync(sums.data(), sums_dev, sums.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPX_HIP_CHECK(h, hipMemcpyAsync(scal, h->d_scal, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-  if (alpha_out) GPX_HIP_CHECK(h, hipMemcpyAsync(alpha_out, alpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, s));
-  GPX_RET(read_info(h, &info));
+  const double* blk;
+  GPX_RET(fetch_block(h, npad + (int64_t)nchunk * NPVv, &blk));
+  const double scal[2] = {blk[0], blk[1]};
+  const int info = reinterpret_cast<const int*>(blk + 8)[0];
+  GPX_RET(check_handover(h, info));
+  const double* sums = blk + GPX_OUT_HEAD + npad;
+  if (alpha_out) memcpy(alpha_out, blk + GPX_OUT_HEAD, (size_t)n * sizeof(double));
   factor_commit(h, p, 0, true);
   if (logp) *logp = -0.5 * scal[1] - scal[0] - 0.5 * (double)n * log(2.0 * M_PI);
 

@@ -234,6 +234,9 @@ struct gpx_handle {
   double* d_vec = nullptr; int64_t vec_cap = 0;
   // gradient workspace: K^-1 (npad x npad, lower tiles), per-workgroup partial sums, final sums
   double* d_kinv = nullptr; int64_t kinv_cap = 0;
+  // set by gpx_lml_grad around its factorisation: accumulate K^-1 += U_{:,k} U_{:,k}^T on the bulk stream as the
+  // panels complete (U = the identity border rows of d_L) instead of one U U^T product after the last panel
+  const double* kinv_U = nullptr; int64_t kinv_rows = 0;
   double* d_gpart = nullptr; int64_t gpart_cap = 0;
   // secondary factor buffers (Cholesky of the posterior covariance for MVN sampling)
   double* d_A2 = nullptr; int64_t a2_cap = 0;
