@@ -173,10 +173,17 @@ int gpx_profile_dump(gpx_handle* h, const char* path);
 int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launches,
                     double* flops, double* bytes);
 
-/* ---- tuning knobs (ints; unknown names -> GPX_ERR_ARG).  "nb" panel width (64 | 128),
- * "lookahead" 0/1, "depth" 1..3 (3 = split-panel schedule, the default), "pair_min" / "quad_min" (group
- * the bulk updates two / four panels at a time while more than this many block columns remain; 0 = never),
- * "graph" 0/1. */
+/* ---- tuning knobs (ints; unknown names -> GPX_ERR_ARG).  Defaults are the measured best on MI355X:
+ *   "nb"           panel width, 64 | 128 (128)
+ *   "lookahead"    0 = everything on one stream, 1 = multi-stream schedules (1)
+ *   "depth"        1 | 2 = classic look-ahead on two / three streams, 3 = split-panel schedule (3)
+ *   "resident"     split-panel schedule: 0 = the chain's kernels hand over at kernel boundaries, 1 = potrf_diag starts
+ *                  resident and sleeps on a device flag, 2 = so does S = A W_k^T (2; falls back to 0 under
+ *                  hardware-counter collection, inside a stream capture and under per-launch bracketing)
+ *   "pair_min" / "quad_min"  group the bulk updates two / four panels at a time while more than this many block
+ *                  columns remain; 0 = never (32 / 48)
+ *   "host_threads" 2 = the panel / bulk streams are fed by a second host thread (1)
+ *   "graph"        1 = replay the fused step from a captured hipGraph (0: measured slower on ROCm 7.2) */
 int gpx_set_option(gpx_handle* h, const char* name, int64_t value);
 int gpx_get_option(gpx_handle* h, const char* name, int64_t* value);
 
