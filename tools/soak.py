@@ -1,0 +1,28 @@
+"""Soak test of the default schedule (in-kernel hand-overs): many steps at several sizes, every result compared
+bitwise with the first one of its size (the schedule is deterministic) and info checked."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gpax_amd
+rng = np.random.default_rng(0)
+c = gpax_amd.Core(0)
+t0 = time.time()
+total = 0
+for n, m, reps in ((300, 17, 400), (700, 50, 400), (1500, 100, 300), (2500, 333, 200), (4096, 1000, 300), (6000, 10, 50)):
+    d = 5
+    x = rng.uniform(-1, 1, (n, d)); xn = rng.uniform(-1, 1, (m, d)); y = rng.standard_normal(n)
+    c.set_train(x); c.set_test(xn); c.set_targets(y, np.ones(m))
+    p = gpax_amd.make_params(1, 1.3, rng.uniform(0.5, 1.5, d), None, np.array([0.01]), 1e-6)
+    ref = None
+    for i in range(reps):
+        c.fit_predict_async(p, 0.0)
+        info, logp, mean, var = c.fetch_results()
+        assert info == 0, (n, i, info)
+        if ref is None: ref = (logp, mean.copy(), var.copy())
+        else: assert logp == ref[0] and np.array_equal(mean, ref[1]) and np.array_equal(var, ref[2]), (n, i)
+        if i % 7 == 0:
+            info, lp, g, a = c.lml_grad(p, y)
+            assert info == 0 and abs(lp - logp) <= 1e-9 * abs(logp), (n, i, lp, logp)
+        total += 1
+    print(f"n={n}: {reps} steps ok, logp={ref[0]:.6f}", flush=True)
+print(f"soak ok: {total} steps in {time.time()-t0:.1f} s")
