@@ -266,6 +266,27 @@ def test_optional_schedule_features_match_the_default(core, option, value):
     assert abs(logp1 - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
 
 
+def test_grouped_schedule_at_default_thresholds_matches_the_oracle(core):
+    """N = 6300 -> 50 block columns of 128: with the default thresholds the bulk updates run four panels at a time
+    (k < 4), then two (k < 18), then one -- the schedule large problems get -- against the oracle's LAPACK path."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, y, xn, p = orc.synthetic_problem(6300, 8, 257, seed=41)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    assert core.get_option("pair_min") == 32 and core.get_option("quad_min") == 48 and core.get_option("nb") == 128
+    core.set_train(x)
+    core.set_test(xn)
+    info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(257), 0.0)
+    assert info == 0
+    logp_ref, mean_ref, var_ref = orc.fit_predict(orc.RBF, x, y, xn, p)
+    assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+    assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
+    info, logp_g, grads, alpha = core.lml_grad(prm, y - 1.0)      # the gradient path groups down to 8 columns
+    assert info == 0 and abs(logp_g - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+    assert all(np.isfinite(v).all() for v in grads.values())
+
+
 def test_full_size_properties(core):
     """BASELINE config C2 (N=4096, d=8, RBF, M=1000) through size-independent properties:
     K symmetric, L L^T = K, logp and posterior against the oracle (LAPACK, ~1 s)."""
