@@ -124,6 +124,7 @@ extern "C" int gpx_dist_configure(gpx_handle* h, int rank, int nranks, const dou
   GPX_RET(dist_ensure(h, &D.send, &D.send_cap, D.chunk_rows * nb));
   GPX_RET(dist_ensure(h, &D.recv, &D.recv_cap, (int64_t)nranks * D.chunk_rows * nb));
   GPX_RET(dist_ensure(h, &D.panel, &D.panel_cap, D.RB * nb * nb));
+  GPX_RET(dist_ensure(h, &D.panel2, &D.panel2_cap, D.RB * nb * nb));
   GPX_RET(dist_ensure(h, &D.xloc, &D.xloc_cap, rows * d));
   GPX_RET(dist_ensure(h, &D.gid, &D.gid_cap, rows));
   GPX_RET(dist_ensure(h, &D.type, &D.type_cap, rows));
@@ -248,29 +249,44 @@ extern "C" int gpx_dist_step_panel(gpx_handle* h, int64_t k) {
   return GPX_OK;
 }
 
-extern "C" int gpx_dist_step_update(gpx_handle* h, int64_t k) {
+static inline double* panel_buf(DistState& D, int64_t k) { return (k & 1) ? D.panel2 : D.panel; }
+
+// after the all-gather: the received chunks (rank-major) into global block order, panel buffer k mod 2
+extern "C" int gpx_dist_step_gather(gpx_handle* h, int64_t k) {
   DistState& D = h->dist;
-  const int nb = h->nb;
   const int64_t nbelow = D.RB - k - 1;
   if (nbelow <= 0) return GPX_OK;
-  hipLaunchKernelGGL(dist_unpermute_kernel, dim3((unsigned)nbelow), dim3(256), 0, h->s_main, D.panel, D.recv, k, D.RB, D.P, nb,
-                     D.chunk_rows);
+  hipLaunchKernelGGL(dist_unpermute_kernel, dim3((unsigned)nbelow), dim3(256), 0, h->s_main, panel_buf(D, k), D.recv, k, D.RB,
+                     D.P, h->nb, D.chunk_rows);
   GPX_HIP_CHECK(h, hipGetLastError());
-  const int64_t s0 = first_slot_after(D, D.rank, k), c0 = k * nb;
-  const int64_t mrows = (D.nloc - s0) * nb;
-  const int64_t ncols = (D.nblk - k - 1) * nb;   // matrix columns right of the panel
-  if (mrows <= 0 || ncols <= 0) return GPX_OK;
-  GemmLaunch t;
-  t.A = D.L + s0 * nb * D.ld + c0; t.lda = D.ld;
-  t.B = D.panel; t.ldb = nb;                     // rows of global blocks k+1 .. (B rows = matrix columns)
-  t.C = D.A + s0 * nb * D.ld + (k + 1) * nb; t.ldc = D.ld;
-  t.M = mrows; t.N = ncols; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
-  t.lower = 1; t.row_off = s0 * nb; t.col_off = (k + 1) * nb; t.b_lower_tri = 0; t.small_tile = 0;
-  t.cyc_P = D.P; t.cyc_r = D.rank; t.cyc_nb = nb;
-  return launch_gemm_nt(h, h->s_main, t);
+  return GPX_OK;
 }
 
-// device buffers the transport moves at step k: W (broadcast from k % P), send -> recv (all-gather)
+// own trailing rows, matrix block columns [cfirst, cfirst + ncol) -= panel k (ncol < 0: all the way to the right);
+// on_trail != 0 enqueues on the bulk stream (the look-ahead driver), else on the main stream
+extern "C" int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t ncol, int on_trail) {
+  DistState& D = h->dist;
+  const int nb = h->nb;
+  if (cfirst < k + 1) cfirst = k + 1;
+  if (ncol < 0 || cfirst + ncol > D.nblk) ncol = D.nblk - cfirst;
+  const int64_t s0 = first_slot_after(D, D.rank, k), c0 = k * nb;
+  const int64_t mrows = (D.nloc - s0) * nb;
+  if (mrows <= 0 || ncol <= 0) return GPX_OK;
+  GemmLaunch t;
+  t.A = D.L + s0 * nb * D.ld + c0; t.lda = D.ld;
+  t.B = panel_buf(D, k) + (cfirst - (k + 1)) * nb * nb; t.ldb = nb;   // rows of global blocks cfirst .. (B rows = matrix columns)
+  t.C = D.A + s0 * nb * D.ld + cfirst * nb; t.ldc = D.ld;
+  t.M = mrows; t.N = ncol * nb; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
+  t.lower = 1; t.row_off = s0 * nb; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 0;
+  t.cyc_P = D.P; t.cyc_r = D.rank; t.cyc_nb = nb;
+  return launch_gemm_nt(h, on_trail ? h->s_trail : h->s_main, t);
+}
+
+extern "C" int gpx_dist_step_update(gpx_handle* h, int64_t k) {
+  GPX_RET(gpx_dist_step_gather(h, k));
+  return gpx_dist_step_update_cols(h, k, k + 1, -1, 0);
+}
+
 extern "C" int gpx_dist_buffers(gpx_handle* h, void** w, int64_t* w_count, void** send, void** recv, int64_t* chunk_count,
                                 void** z, int64_t* z_count) {
   if (!h || !h->dist.configured) return GPX_ERR_STATE;
@@ -392,14 +408,36 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
   hipStream_t s = h->s_main;
   const int nb = h->nb;
   GPX_RET(gpx_dist_build(h, p, new_noise));
+  // Look-ahead (depth 1): the main stream carries factor -> broadcast -> panel -> all-gather -> update of block column
+  // k+1 only; the bulk update of the columns >= k+2 runs on the second stream while the NEXT step's diagonal block,
+  // broadcast, panel solve and all-gather are already under way -- the collectives' latency (the per-step cost that
+  // does not shrink with the rank count) hides behind the bulk update.  Column k+2 goes back to the main stream one
+  // step later, so the only wait on the critical path is for the PREVIOUS step's bulk update.
+  static int dist_la = -1;
+  if (dist_la < 0) { const char* e = getenv("GPX_DIST_LOOKAHEAD"); dist_la = e ? atoi(e) : 1; }
+  hipStream_t t = h->s_trail;
+  while ((int64_t)D.ev_s.size() < D.nblk) {
+    hipEvent_t a, b;
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming | hipEventDisableSystemFence));
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, hipEventDisableTiming | hipEventDisableSystemFence));
+    D.ev_s.push_back(a); D.ev_t.push_back(b);
+  }
   for (int64_t k = 0; k < D.nblk; ++k) {
     GPX_RET(gpx_dist_step_diag(h, k));
     if (D.P > 1) GPX_NCCL_CHECK(h, ncclBroadcast(D.W, D.W, (size_t)nb * nb, ncclDouble, (int)owner_of(D, k), comm, s));
     GPX_RET(gpx_dist_step_panel(h, k));
     if (D.P > 1) GPX_NCCL_CHECK(h, ncclAllGather(D.send, D.recv, (size_t)(D.chunk_rows * nb), ncclDouble, comm, s));
     else GPX_HIP_CHECK(h, hipMemcpyAsync(D.recv, D.send, (size_t)(D.chunk_rows * nb) * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GPX_RET(gpx_dist_step_update(h, k));
+    if (!dist_la) { GPX_RET(gpx_dist_step_update(h, k)); continue; }
+    GPX_RET(gpx_dist_step_gather(h, k));
+    if (k >= 1) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)(k - 1)], 0));   // column k+1 was last written by the bulk update of step k-1
+    GPX_RET(gpx_dist_step_update_cols(h, k, k + 1, 1, 0));
+    GPX_HIP_CHECK(h, hipEventRecord(D.ev_s[(size_t)k], s));
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(t, D.ev_s[(size_t)k], 0));
+    GPX_RET(gpx_dist_step_update_cols(h, k, k + 2, -1, 1));
+    GPX_HIP_CHECK(h, hipEventRecord(D.ev_t[(size_t)k], t));
   }
+  if (dist_la && D.nblk > 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)(D.nblk - 1)], 0));
   GPX_RET(gpx_dist_extract_z(h));
   if (D.P > 1) GPX_NCCL_CHECK(h, ncclBroadcast(D.z, D.z, (size_t)D.npad, ncclDouble, D.r_owner, comm, s));
   const int64_t nt = (int64_t)D.test_rows.size();
@@ -434,7 +472,10 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
 
 void gpx_dist_free(gpx_handle* h) {
   DistState& D = h->dist;
-  void* bufs[] = {D.A, D.L, D.W, D.send, D.recv, D.panel, D.xloc, D.gid, D.type, D.r, D.z, D.small, D.red};
+  for (auto e : D.ev_s) (void)hipEventDestroy(e);
+  for (auto e : D.ev_t) (void)hipEventDestroy(e);
+  D.ev_s.clear(); D.ev_t.clear();
+  void* bufs[] = {D.A, D.L, D.W, D.send, D.recv, D.panel, D.panel2, D.xloc, D.gid, D.type, D.r, D.z, D.small, D.red};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (D.comm) (void)ncclCommDestroy((ncclComm_t)D.comm);
   D = DistState();

@@ -150,6 +150,9 @@ struct DistState {
   int64_t n = 0, m = 0, npad = 0, nblk = 0, eblk = 0, RB = 0, nloc = 0, ld = 0, chunk_rows = 0;
   int kind = 0; double k_scale = 0, k_jitter = 0;
   double *A = nullptr, *L = nullptr, *W = nullptr, *send = nullptr, *recv = nullptr, *panel = nullptr;
+  double* panel2 = nullptr; int64_t panel2_cap = 0;   // panels alternate between two buffers: the bulk update of step k still
+                                                        // reads panel k while step k+1 gathers the next one (look-ahead)
+  std::vector<hipEvent_t> ev_s, ev_t;                   // look-ahead hand-overs of the RCCL driver
   double *xloc = nullptr, *r = nullptr, *z = nullptr, *small = nullptr, *red = nullptr;
   int64_t* gid = nullptr; int* type = nullptr;
   int64_t a_cap = 0, l_cap = 0, w_cap = 0, send_cap = 0, recv_cap = 0, panel_cap = 0, xloc_cap = 0, r_cap = 0, z_cap = 0,

@@ -94,8 +94,10 @@ class LoopbackGroup:
                 for r in range(self.P):
                     dst = bufs[q]["recv"] + r * bufs[q]["chunk"] * 8
                     R[q].core._check(R[q].lib.gpx_dist_copy(R[q].h, dst, bufs[r]["send"], bufs[q]["chunk"]), "allgather")
-            for r in R:
-                r.core._check(r.lib.gpx_dist_step_update(r.h, k), "step_update")
+            for r in R:  # the look-ahead driver's split of the update: block column k+1 first, then the rest
+                r.core._check(r.lib.gpx_dist_step_gather(r.h, k), "step_gather")
+                r.core._check(r.lib.gpx_dist_step_update_cols(r.h, k, k + 1, 1, 0), "step_update_cols (next)")
+                r.core._check(r.lib.gpx_dist_step_update_cols(r.h, k, k + 2, -1, 0), "step_update_cols (rest)")
                 r.core.synchronize()
         owner = R[0].r_owner
         R[owner].core._check(R[owner].lib.gpx_dist_extract_z(R[owner].h), "extract_z")

@@ -36,7 +36,12 @@ int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, const double
 int gpx_dist_build(gpx_handle* h, const gpx_kernel_params* p, double new_noise);
 int gpx_dist_step_diag(gpx_handle* h, int64_t k);     /* owner of block k: potrf_diag -> W_k */
 int gpx_dist_step_panel(gpx_handle* h, int64_t k);    /* after W_k arrived: own panel rows, packed into `send` */
-int gpx_dist_step_update(gpx_handle* h, int64_t k);   /* after the all-gather: own trailing rows */
+int gpx_dist_step_update(gpx_handle* h, int64_t k);   /* after the all-gather: own trailing rows (= gather + update_cols of everything) */
+/* the two halves of gpx_dist_step_update, for look-ahead schedules: the received chunks into block order (panel
+ * buffer k mod 2), then the update of the matrix block columns [cfirst, cfirst+ncol) (ncol < 0: to the right edge)
+ * on the main (on_trail = 0) or the bulk stream */
+int gpx_dist_step_gather(gpx_handle* h, int64_t k);
+int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t ncol, int on_trail);
 int gpx_dist_buffers(gpx_handle* h, void** w, int64_t* w_count, void** send, void** recv, int64_t* chunk_count,
                      void** z, int64_t* z_count);
 int gpx_dist_copy(gpx_handle* h, void* dst, const void* src, int64_t count);   /* device-to-device, doubles */
