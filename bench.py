@@ -291,7 +291,21 @@ def main():
                 logp_ref, mean_ref, var_ref = orc.fit_predict(kind, x, y, x_new, p)
                 times.append(time.perf_counter() - c0)
             t_cpu = float(np.median(times))
+            cpu_model, blas = "unknown", "unknown"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+            except Exception:
+                pass
+            try:
+                from threadpoolctl import threadpool_info
+
+                blas = "; ".join(f"{i.get('internal_api')} {i.get('version')} ({i.get('num_threads')} threads)"
+                                 for i in threadpool_info() if i.get("user_api") == "blas")
+            except Exception:
+                pass
             out["cpu_baseline"] = {
+                "cpu_model": cpu_model, "blas": blas,
                 "value": n / t_cpu,
                 "unit": "points/s",
                 "cores": os.cpu_count(),
