@@ -92,7 +92,9 @@ def _leapfrog(vg, u, r, grad, eps, minv):
 
 
 def _energy(logp, r, minv):
-    return -logp + 0.5 * float(r @ (minv * r))
+    with np.errstate(over="ignore", invalid="ignore"):   # a wild trial step of the step-size search: rejected as inf
+        h = -logp + 0.5 * float(r @ (minv * r))
+    return h if np.isfinite(h) else np.inf
 
 
 def _reasonable_step(vg, u, logp, grad, minv, rng, eps=1.0):
