@@ -287,7 +287,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
     return GPX_ERR_UNSUPPORTED;
   }
   const char* env;
-  if ((env = getenv("GPX_NB"))) h->nb = atoi(env) == 64 ? 64 : 128;
+  if ((env = getenv("GPX_NB"))) { h->nb = atoi(env) == 64 ? 64 : 128; h->nb_auto = false; }
   if ((env = getenv("GPX_LOOKAHEAD"))) h->lookahead = atoi(env) != 0;
   if ((env = getenv("GPX_GRAPH"))) h->use_graph = atoi(env) != 0;
   if ((env = getenv("GPX_DEPTH"))) h->depth = std::min(std::max(atoi(env), 1), 3);
@@ -353,8 +353,10 @@ extern "C" int gpx_synchronize(gpx_handle* h) {
 extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!h || !name) return GPX_ERR_ARG;
   if (!strcmp(name, "nb")) {
-    if (value != 64 && value != 128) { gpx_set_error(h, "nb must be 64 or 128"); return GPX_ERR_ARG; }
-    if (h->nb != (int)value) { h->nb = (int)value; h->have_factor = false; }
+    if (value != 0 && value != 64 && value != 128) { gpx_set_error(h, "nb must be 64, 128 or 0 (automatic)"); return GPX_ERR_ARG; }
+    const int nv = value ? (int)value : ((h->n > 0 && h->n <= 64) ? 64 : 128);
+    h->nb_auto = value == 0;
+    if (h->nb != nv) { h->nb = nv; h->have_factor = false; }
     return GPX_OK;
   }
   if (!strcmp(name, "lookahead")) { h->lookahead = value != 0; return GPX_OK; }
@@ -492,6 +494,7 @@ extern "C" int gpx_set_train(gpx_handle* h, const double* x, int64_t n, int32_t 
   GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
   if (h->d != d) { h->m = 0; }
   h->n = n; h->d = d;
+  if (h->nb_auto) h->nb = n <= 64 ? 64 : 128;
   h->have_factor = false; h->have_z = false; h->have_r = false;
   return GPX_OK;
 }
@@ -594,10 +597,12 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
 // U = L^-T); border block j is still all-zero in the panels k < j, so step k only carries rows
 // below tri_base + (k+1)*nb -- the triangular inverse costs N^3/3 flops instead of N^3.
 static int factor_loop(gpx_handle* h, int64_t rows_total, int64_t tri_base = -1) {
-  if (h->lookahead != 0 && h->depth >= 3) return factor_loop_split(h, rows_total, tri_base);
+  // one block column (n <= nb): potrf_diag and the border rows' panel solve, nothing to overlap -- one stream,
+  // no events (the multi-stream machinery costs ~20 us of hand-overs on a ~60 us step)
+  if (h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= 2) return factor_loop_split(h, rows_total, tri_base);
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld;
   const int64_t nblk = npad / nb;
-  const bool la = h->lookahead != 0;
+  const bool la = h->lookahead != 0 && nblk >= 2;
   const int D = la ? (h->depth >= 2 ? 2 : 1) : 1;
   hipStream_t P = h->s_main, T = la ? h->s_trail : h->s_main, Q = (la && D >= 2) ? h->s_far : h->s_main;
   double* A = h->d_A; double* L = h->d_L;
@@ -1253,7 +1258,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   const double* U = h->d_L + (npad + RZ) * ld;
   // K^-1 = U U^T (lower 64x64 tiles) is accumulated panel by panel inside the split-panel schedule; the classic
   // schedules (options "depth" 1|2, "lookahead" 0) form it in one product after the factorisation
-  const bool fused_kinv = h->lookahead != 0 && h->depth >= 3;
+  const bool fused_kinv = h->lookahead != 0 && h->depth >= 3 && npad / nb >= 2;   // same test as factor_loop's dispatch
   if (fused_kinv) { h->kinv_U = U; h->kinv_rows = n64; }
   int frc = factor_loop(h, rows, npad + RZ);
   h->kinv_U = nullptr; h->kinv_rows = 0;
@@ -1430,12 +1435,17 @@ extern "C" int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* c
   if (!cov || !eps || !out || m <= 0 || nsamp <= 0) { gpx_set_error(h, "gpx_mvn_sample: bad argument"); return GPX_ERR_ARG; }
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
   hipStream_t s = h->s_main;
-  const int64_t nb = h->nb, npad = round_up(m, nb), spad = round_up(nsamp, 64);
+  const int sv_nb = h->nb;
+  const int64_t nb = h->nb_auto ? (m <= 64 ? 64 : 128) : h->nb;   // the sample covariance is its own problem size
+  const int64_t npad = round_up(m, nb), spad = round_up(nsamp, 64);
   GPX_RET(ensure(h, &h->d_A2, &h->a2_cap, npad * npad));
   GPX_RET(ensure(h, &h->d_L2, &h->l2_cap, npad * npad));
   GPX_RET(ensure(h, &h->d_W2, &h->w2_cap, npad * nb));
   GPX_RET(ensure(h, &h->d_S, &h->s_cap, 2 * spad * npad));
-  GPX_RET(ensure_events(h, (size_t)(npad / nb)));
+  h->nb = (int)nb;
+  int erc = ensure_events(h, (size_t)(npad / nb));   // sizes its scratch by h->nb
+  h->nb = sv_nb;
+  GPX_RET(erc);
   GPX_HIP_CHECK(h, hipMemcpy2DAsync(h->d_A2, (size_t)npad * sizeof(double), cov, (size_t)m * sizeof(double),
                                     (size_t)m * sizeof(double), (size_t)m, hipMemcpyHostToDevice, s));
   GPX_RET(launch_fill_identity_pad(h, s, h->d_A2, npad, m, npad, npad));
@@ -1443,10 +1453,10 @@ extern "C" int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* c
   // run the factor loop on the secondary buffers
   std::swap(h->d_A, h->d_A2); std::swap(h->d_L, h->d_L2); std::swap(h->d_W, h->d_W2);
   const int64_t sv_npad = h->npad, sv_ld = h->ld, sv_epad = h->epad;
-  h->npad = npad; h->ld = npad; h->epad = 0;
+  h->npad = npad; h->ld = npad; h->epad = 0; h->nb = (int)nb;
   int rc = factor_loop(h, npad);
   double* Lc = h->d_L;
-  h->npad = sv_npad; h->ld = sv_ld; h->epad = sv_epad;
+  h->npad = sv_npad; h->ld = sv_ld; h->epad = sv_epad; h->nb = sv_nb;
   std::swap(h->d_A, h->d_A2); std::swap(h->d_L, h->d_L2); std::swap(h->d_W, h->d_W2);
   GPX_RET(rc);
   double* E = h->d_S; double* Y = h->d_S + spad * npad;

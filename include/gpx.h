@@ -174,7 +174,7 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
                     double* flops, double* bytes);
 
 /* ---- tuning knobs (ints; unknown names -> GPX_ERR_ARG).  Defaults are the measured best on MI355X:
- *   "nb"           panel width, 64 | 128 (128)
+ *   "nb"           panel width, 64 | 128, or 0 = automatic: 64 for n <= 64, else 128 (0)
  *   "lookahead"    0 = everything on one stream, 1 = multi-stream schedules (1)
  *   "depth"        1 | 2 = classic look-ahead on two / three streams, 3 = split-panel schedule (3)
  *   "resident"     split-panel schedule: 0 = the chain's kernels hand over at kernel boundaries, 1 = potrf_diag starts

@@ -36,6 +36,8 @@ def _problem(n, d, seed):
 CASES = [
     # kind, n, d, ard_length, ard_period, noise
     (0, 25, 1, False, False, 0.006744897501960818),
+    (0, 60, 2, True, False, 0.02),        # one block column at either panel width
+    (1, 128, 3, True, False, 0.03),
     (0, 300, 3, True, False, 0.05),
     (0, 517, 8, False, False, 0.01),
     (0, 640, 20, True, False, 0.02),      # two dimension chunks
@@ -49,7 +51,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("kind,n,d,ard_l,ard_p,noise", CASES)
-@pytest.mark.parametrize("nb", [64, 128])
+@pytest.mark.parametrize("nb", [0, 64, 128])
 def test_lml_grad_matches_oracle(core, kind, n, d, ard_l, ard_p, noise, nb):
     import gpax_amd
     from oracle import gp_oracle as orc
@@ -62,7 +64,7 @@ def test_lml_grad_matches_oracle(core, kind, n, d, ard_l, ard_p, noise, nb):
     core.set_train(x)
     p = gpax_amd.make_params(kind, k_scale, k_length, k_period, np.array([noise]), 1e-6, True)
     info, logp, grads, alpha = core.lml_grad(p, r)
-    core.set_option("nb", 128)
+    core.set_option("nb", 0)   # automatic again
     assert info == 0
     logp_ref, g_ref, alpha_ref = orc.lml_grad(kind, x, r, k_scale, k_length, k_period, noise, 1e-6)
     assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)

@@ -85,7 +85,7 @@ def test_fused_fit_predict_matches_golden(core, name, lookahead):
     """lookahead 0: one stream; 1: classic look-ahead (two streams); 2: depth-2 (three streams); 3: split panel
     (the default: the chain stream carries only the diagonal band)."""
     g = load_golden(name)
-    core.set_option("nb", 128)
+    core.set_option("nb", 0)   # automatic again
     core.set_option("lookahead", 1 if lookahead else 0)
     core.set_option("depth", max(lookahead, 1))
     core.set_train(g["x"])
@@ -110,7 +110,7 @@ def test_graph_replay_tracks_hyperparameters(core):
     from oracle import gp_oracle as orc
 
     x, y, xn, p = orc.synthetic_problem(300, 4, 21, seed=11)
-    core.set_option("nb", 128)
+    core.set_option("nb", 0)   # automatic again
     core.set_train(x)
     core.set_test(xn)
     for graph in (1, 0, 1):
@@ -171,7 +171,7 @@ def test_against_oracle_seeded(core, n, d, kind):
     from oracle import gp_oracle as orc
 
     x, y, xn, p = orc.synthetic_problem(n, d, 37, seed=n + d, kind=kind)
-    core.set_option("nb", 128)
+    core.set_option("nb", 0)   # automatic again
     core.set_train(x)
     core.set_test(xn)
     prm = gpax_amd.make_params(kind, p["k_scale"], p["k_length"], p.get("k_period"), p["k_noise"], p["k_jitter"])
@@ -230,7 +230,7 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
     core.set_test(xn)
     _, _, l = core.fit_factor(prm, want_l=True)
     info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(77), 0.0)
-    core.set_option("nb", 128)
+    core.set_option("nb", 0)   # automatic again
     core.set_option("pair_min", 32)
     core.set_option("quad_min", 48)
     assert info == 0
@@ -296,7 +296,7 @@ def test_full_size_properties(core):
     n, d, m = 4096, 8, 1000
     x, y, xn, p = orc.synthetic_problem(n, d, m, seed=0)
     prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
-    core.set_option("nb", 128)
+    core.set_option("nb", 0)   # automatic again
     core.set_train(x)
     core.set_test(xn)
     info, k, l = core.fit_factor(prm, want_k=True, want_l=True)
