@@ -724,7 +724,8 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   const bool resident = h->resident != 0 && !h->in_capture && h->prof_mode != 1 && nblk >= 3;
   hipStream_t P2 = resident ? h->s_main2 : P;
   const unsigned n_signal = (unsigned)((nb / 32) * (nb / 32 + 1) / 2);   // lower 32x32 tiles of a diagonal block
-  if (resident) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(2 * nblk) * sizeof(unsigned), P));
+  if (resident && !h->flags_clean) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(2 * nblk) * sizeof(unsigned), P));
+  h->flags_clean = false;
   // resident == 2: every hand-over of the chain is in-kernel.  The diagonal blocks run on one stream, the two band
   // kernels on the other; S = A W_k^T is launched while potrf_diag(k) still runs and sleeps on the flag that kernel
   // raises after its last (write-through) store of W_k -- the ~11 us from potrf_diag's last instruction to the
@@ -778,6 +779,20 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
                               (chain2 && need_w && k + 1 < nblk) ? flagsW + k : nullptr));
     prof_end(h, P);
     if (!need_w) return GPX_OK;
+    if (k + 1 >= nblk && !kinv) {
+      // the last panel is the border rows only and nothing follows it but the epilogue: it runs on the chain stream,
+      // behind potrf_diag, instead of hopping to the panel stream and back (two ~8 us event hand-overs)
+      GemmLaunch g;
+      g.A = A + r0 * ld + c0; g.lda = ld;
+      g.B = h->d_W + k * nb * nb; g.ldb = nb;
+      g.C = L + r0 * ld + c0; g.ldc = ld;
+      g.M = rows - r0; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+      g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+      prof_begin(h, P, GPX_STAGE_TRSM_PANEL, (double)g.M * nb * nb, 8.0 * (2.0 * g.M * nb + nb * nb));
+      GPX_RET(launch_gemm_nt(h, P, g));
+      prof_end(h, P);
+      return GPX_OK;   // (the gradient path keeps its last panel on Q: the K^-1 update behind it belongs to T's sequence)
+    }
     if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
     w_rec[(size_t)k].store(1, std::memory_order_release);
     if (k + 1 >= nblk) return GPX_OK;
@@ -828,6 +843,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
     const int64_t mrows = rows - r0;
     if (mrows <= 0) return GPX_OK;
+    if (k + 1 >= nblk && !kinv) return GPX_OK;   // the last panel (border rows only) is launched by the chain itself
     if (!await(w_rec[(size_t)k])) return GPX_ERR_HIP;
     // (Starting the panel kernel resident too -- it would sleep on potrf_diag's flag instead of waiting ~8 us for the
     // cross-stream event -- crowds the bulk update with sleeping workgroups: 1.76 -> 1.81 ms, not used.)
@@ -1032,7 +1048,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     if (m_rows <= 0) return GPX_OK;
     GramLaunch c = g;
     c.x1 = h->d_xnew; c.n1 = m_rows; c.out = h->d_A + npad * ld; c.lower_only = 0; c.diag_rule = 0;
-    c.noise = nullptr; c.zero_info = nullptr; c.col0 = 0; c.x2 = h->d_x; c.n2 = n;
+    c.noise = nullptr; c.zero_info = nullptr; c.zero_flags = nullptr; c.col0 = 0; c.x2 = h->d_x; c.n2 = n;
     c.start_event = c.stop_event = nullptr;
     prof_begin(h, st, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(fp.kind, d) * m_rows * n,
                8.0 * m_rows * n + 8.0 * (m_rows + n) * d);
@@ -1042,6 +1058,10 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   };
   double fl, by;
   g.zero_info = h->d_info;
+  if (h->d_flags) {   // the hand-over flags of the split-panel schedule are cleared by the same launch
+    g.zero_flags = h->d_flags; g.n_zero_flags = (int)(2 * (npad / h->nb));
+    h->flags_clean = true;
+  }
   gram_cost(0, n, &fl, &by);
   (void)prof_pair(h, GPX_STAGE_GRAM, fl, by, &g.start_event, &g.stop_event);
   GPX_RET(launch_gram(h, s, g));
@@ -1056,7 +1076,9 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   // that stream.)
   GPX_RET(launch_border_rows(h, s, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
 
-  GPX_RET(factor_loop(h, rows));
+  const int lrc = factor_loop(h, rows);
+  h->flags_clean = false;   // consumed by the split-panel loop, or unused by the others: never carried into another call
+  GPX_RET(lrc);
 
   return GPX_OK;   // z = L^-1 r (row npad + m_rows of d_L) is copied to d_z by the fused epilogue of the caller
 }

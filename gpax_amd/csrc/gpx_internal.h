@@ -63,6 +63,7 @@ struct GramLaunch {
   double jitter;
   int64_t col0 = 0;     // x2 / out are the column slice starting at this global column (lower test, diagonal rule)
   int* zero_info = nullptr;  // device int cleared by the launch
+  unsigned* zero_flags = nullptr; int n_zero_flags = 0;   // device flag words cleared by the launch
   hipEvent_t start_event = nullptr, stop_event = nullptr;   // the kernel's own dispatch timestamps (profiling)
 };
 int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& g);
@@ -190,7 +191,8 @@ struct gpx_handle {
   int device = 0;
   hipStream_t s_main = nullptr, s_trail = nullptr, s_far = nullptr;
   hipStream_t s_main2 = nullptr;   // second chain stream: consecutive diagonal blocks alternate, so the next potrf_diag can already be resident
-  unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per-step tile counters of the resident start
+  unsigned* d_flags = nullptr; int64_t flags_cap = 0;
+  bool flags_clean = false;   // the flags were cleared by the gram launch of this call (no memset needed)   // per-step tile counters of the resident start
   hipEvent_t ev_chain2 = nullptr;
   int resident = 2;                // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
                                    // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag)

@@ -36,6 +36,7 @@ struct GramArgs {
   double k_scale, noise_scalar, jitter;
   int64_t col0;      // global index of x2's first row / out's first column (column slices of one matrix)
   int* zero_info;    // when set, workgroup (0,0) clears it (saves the factorisation a memset launch)
+  unsigned* zero_flags; int n_zero_flags;   // likewise: the hand-over flags of the split-panel schedule
 };
 
 template <int KIND, bool VEC2>
@@ -48,7 +49,10 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 
   const int tid = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
-  if (g.zero_info && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *g.zero_info = 0;
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (g.zero_info && tid == 0) *g.zero_info = 0;
+    if (g.zero_flags) for (int i = tid; i < g.n_zero_flags; i += 256) g.zero_flags[i] = 0u;
+  }
   if (g.lower_only && g.col0 + j0 > i0 + GT - 1) return;
 
   const int cj = tid & 31;   // column pair: cols 2cj, 2cj+1
@@ -152,7 +156,7 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   g.n1 = L.n1; g.n2 = L.n2; g.ld = L.ld; g.d = L.d;
   g.lower_only = L.lower_only; g.diag_rule = L.diag_rule;
   g.k_scale = L.k_scale; g.noise_scalar = L.noise_scalar; g.jitter = L.jitter;
-  g.col0 = L.col0; g.zero_info = L.zero_info;
+  g.col0 = L.col0; g.zero_info = L.zero_info; g.zero_flags = L.zero_flags; g.n_zero_flags = L.n_zero_flags;
   dim3 grid((unsigned)((L.n2 + GT - 1) / GT), (unsigned)((L.n1 + GT - 1) / GT));
   const bool vec2 = (L.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(L.out) & 15) == 0);
 #define GPX_GRAM_LAUNCH(KIND)                                                        \
