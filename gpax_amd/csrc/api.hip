@@ -238,10 +238,14 @@ static hipError_t create_streams(gpx_handle* h) {
   const int ncu = h->prop.multiProcessorCount;
   int drop = env ? atoi(env) : 0;   // measured: no gain once the bulk kernel is released after the near look-ahead
   if (drop > 0 && drop < ncu) {
-    // spread the EXCLUDED CUs evenly over the mask order
+    // Mask bit i is CU i/8 of XCD i%8 (measured: excluding every 16th bit halves ONE XCD and the bulk kernel, whose
+    // workgroups are dealt round-robin over the XCDs, slows to that XCD's pace).  The first `drop` bits (a multiple
+    // of 8) therefore take drop/8 CUs from every XCD.  GPX_RESERVED_SPREAD=1: the old every-(ncu/drop)-th rule.
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    const bool spread = getenv("GPX_RESERVED_SPREAD") && atoi(getenv("GPX_RESERVED_SPREAD")) != 0;
+    if (!spread) drop = (drop + 7) / 8 * 8;
     for (int i = 0; i < ncu; ++i) {
-      const bool excluded = ((int64_t)i * drop / ncu) != ((int64_t)(i + 1) * drop / ncu);
+      const bool excluded = spread ? ((int64_t)i * drop / ncu) != ((int64_t)(i + 1) * drop / ncu) : i < drop;
       if (!excluded) mask[(size_t)i / 32] |= 1u << (i % 32);
     }
     // only the bulk stream T is kept off the reserved CUs (GPX_RESERVED_Q=1: the panel stream Q too)

@@ -133,6 +133,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     int64_t ti, tj;
     if (!tile_from_block(g, ti, tj)) return;
     m0 = ti * BM; n0 = tj * BN;
+  } else if (g.map_S < 0) {
+    // 1-D row-major enumeration of the lower trapezoid's tiles (row_off == col_off): no empty workgroups, and the
+    // round-robin deal of consecutive workgroup ids over the 8 XCDs stays balanced whatever the grid width (with
+    // the 2-D grid and a width that is a multiple of 8 tiles, XCD x owns the tile columns = x mod 8 and XCD 0
+    // gets 25 % more of the triangle than XCD 7: tools/gemm_shape, 33 vs 42 TFLOP/s at 4096 vs 3968 rows)
+    const int64_t id = blockIdx.x, ntj = g.map_ntj, ntri = ntj * (ntj + 1) / 2;
+    int64_t ti, tj;
+    if (id < ntri) {
+      ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+      while (ti * (ti + 1) / 2 > id) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+      tj = id - ti * (ti + 1) / 2;
+    } else {
+      ti = ntj + (id - ntri) / ntj; tj = (id - ntri) % ntj;
+    }
+    m0 = ti * BM; n0 = tj * BN;
   } else if (g.lower && (tile_global_row(g, m0) + BM - 1 < g.col_off + n0)) {
     return;  // tile strictly above the diagonal
   }
@@ -482,10 +498,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   }
 }
 
-static bool gemm_tile_map_enabled() {
+// GPX_TILE_MAP: 0 (default) 1-D row-major enumeration of the lower trapezoid, 1 XCD-aware super-tiles, 2 plain 2-D grid
+static int gemm_tile_map_mode() {
   static int on = -1;
   if (on < 0) { const char* e = getenv("GPX_TILE_MAP"); on = e ? atoi(e) : 0; }
-  return on != 0;
+  return on;
 }
 
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
@@ -531,7 +548,15 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
   }
-  if (!L.small_tile && L.variant == 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && gemm_tile_map_enabled()) {
+  if (!L.small_tile && L.variant == 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && gemm_tile_map_mode() == 0) {
+    const int64_t nti = L.M / 64, ntj = L.N / 64;
+    g.map_S = -1; g.map_nti = nti; g.map_ntj = ntj;
+    const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
+    hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    GPX_HIP_CHECK(h, hipGetLastError());
+    return GPX_OK;
+  }
+  if (!L.small_tile && L.variant == 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && gemm_tile_map_mode() == 1) {
     const int64_t nti = L.M / 64, ntj = L.N / 64;
     int S = 1;
     static int forced = -1;

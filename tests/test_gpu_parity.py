@@ -343,3 +343,85 @@ def test_call_order_errors(core):
     with pytest.raises(gpax_amd.GpxError):
         c.fit_factor(gpax_amd.make_params(2, 1.0, 1.0))  # periodic without k_period (reference quirk F7)
     c.close()
+
+
+def _solve_identity(core, kind, x, r, prm, noise_plus_jitter, n_probe, m_total, seed):
+    """Size-independent check of factorisation + solves + cross-gram + posterior mean: predicting AT training
+    points x_i gives mean_i - m_i = k(x_i, X) alpha = r_i - (k_noise + k_jitter) alpha_i, because K alpha = r and
+    the cross-covariance carries no diagonal term (gpax/gp.py:282, apply_noise=False).  alpha comes from
+    gpx_lml_grad (U z, a different code path from the border rows that carry the posterior)."""
+    rng = np.random.default_rng(seed)
+    n = x.shape[0]
+    idx = rng.choice(n, n_probe, replace=False)
+    x_new = np.concatenate([x[idx], rng.uniform(x.min(), x.max(), (m_total - n_probe, x.shape[1]))])
+    core.set_train(x)
+    core.set_test(x_new)
+    info, logp, mean, var = core.fit_predict(prm, r, np.zeros(m_total), 0.0)
+    assert info == 0 and np.isfinite(logp)
+    info2, logp2, mean2, var2 = core.fit_predict(prm, r, np.zeros(m_total), 0.0)
+    assert info2 == 0 and logp2 == logp and np.array_equal(mean, mean2) and np.array_equal(var, var2)   # idempotent, bit for bit
+    info, logp_g, _, alpha = core.lml_grad(prm, r)
+    assert info == 0 and abs(logp_g - logp) <= 1e-9 * abs(logp)
+    resid = mean[:n_probe] + noise_plus_jitter * alpha[idx] - r[idx]
+    scale = max(1.0, np.abs(r).max(), noise_plus_jitter * np.abs(alpha).max())
+    assert np.abs(resid).max() <= 1e-7 * scale, np.abs(resid).max()
+    assert (var > 0).all() and (var[:n_probe] <= noise_plus_jitter * (1 + 1e-6)).all()   # 0 < var_i <= noise at a training point
+    return logp, alpha
+
+
+def test_full_size_properties_c3(core):
+    """BASELINE config C3 (Matern-5/2, d=16, N=16384) at full size, without the oracle (too slow there):
+    L L^T v = K v on random probe vectors, sum log L_ii and r^T alpha against logp, and the solve identity."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    n, d, m = 16384, 16, 1000
+    x, y, _, p = orc.synthetic_problem(n, d, m, seed=3, kind=1)
+    prm = gpax_amd.make_params(1, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    core.set_option("nb", 0)
+    r = y - 1.0
+    nj = float(p["k_noise"][0] + p["k_jitter"][0])
+    logp, alpha = _solve_identity(core, 1, x, r, prm, nj, 400, m, seed=5)
+    info, k, l = core.fit_factor(prm, want_k=True, want_l=True)
+    assert info == 0 and np.array_equal(l, np.tril(l))
+    rng = np.random.default_rng(6)
+    v = rng.standard_normal((n, 3))
+    kv = k @ v
+    assert np.abs(l @ (l.T @ v) - kv).max() <= 1e-10 * np.abs(kv).max()
+    logp_host = -0.5 * float(r @ alpha) - float(np.log(np.diag(l)).sum()) - 0.5 * n * np.log(2 * np.pi)
+    assert abs(logp - logp_host) <= 1e-9 * abs(logp_host)
+
+
+def test_full_size_properties_c5(core):
+    """BASELINE config C5 (structured mean, Matern-5/2, d=2, N=8192, 10 000 candidates) at full size: solve identity
+    with the piecewise prior mean (examples/04_Structured_GP.ipynb cell 10) and analytic EI finite and >= 0."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+    from scipy.special import ndtr
+
+    n, d, m = 8192, 2, 10000
+    rng = np.random.default_rng(11)
+    x = rng.uniform(0.0, 3.0, (n, d))
+    y = orc.piecewise_mean(x) + 0.05 * rng.standard_normal(n)
+    prm = gpax_amd.make_params(1, 1.0, np.array([1.0]), None, np.array([0.01]), 1e-6)
+    core.set_option("nb", 0)
+    r = y - orc.piecewise_mean(x)
+    _solve_identity(core, 1, x, r, prm, 0.01 + 1e-6, 500, m, seed=12)
+    info, mean, var, _ = core.posterior(np.full(m, 0.25), 0.0)   # cached factor, another prior mean vector
+    assert info == 0
+    sd, y_max = np.sqrt(var), float(y.max())
+    u = (mean - y_max) / sd
+    ei = sd * np.exp(-0.5 * u * u) / np.sqrt(2 * np.pi) + (mean - y_max) * ndtr(u)   # gpax/acquisition.py:291-298
+    assert np.isfinite(ei).all() and (ei >= -1e-12).all()
+
+
+def test_full_size_properties_c4_one_gpu(core):
+    """BASELINE config C4's matrix (RBF, d=8, N=32768) on ONE GPU: the solve identity only (K and L are 8.6 GB each)."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    n, d, m = 32768, 8, 1000
+    x, y, _, p = orc.synthetic_problem(n, d, m, seed=4)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    core.set_option("nb", 0)
+    _solve_identity(core, 0, x, y - 1.0, prm, float(p["k_noise"][0] + p["k_jitter"][0]), 400, m, seed=8)

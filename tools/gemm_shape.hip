@@ -7,7 +7,7 @@ void gpx_set_error(gpx_handle*, const std::string& m) { printf("error: %s\n", m.
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP %s line %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv) {
   const int64_t M = atoll(argv[1]), N = atoll(argv[2]);
-  const int64_t ld = N + 1024;
+  const int64_t ld = N + (getenv("LDPAD") ? atoll(getenv("LDPAD")) : 1024);
   double *A, *L; CK(hipMalloc(&A, M * ld * 8)); CK(hipMalloc(&L, M * ld * 8));
   CK(hipMemset(A, 0, M * ld * 8)); CK(hipMemset(L, 0, M * ld * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
