@@ -257,7 +257,7 @@ extern "C" int gpx_dist_step_gather(gpx_handle* h, int64_t k) {
   const int64_t nbelow = D.RB - k - 1;
   if (nbelow <= 0) return GPX_OK;
   hipLaunchKernelGGL(dist_unpermute_kernel, dim3((unsigned)nbelow), dim3(256), 0, h->s_main, panel_buf(D, k), D.recv, k, D.RB,
-                     D.P, h->nb, D.chunk_rows);
+                     D.P, h->nb, D.gather_stride_rows > 0 ? D.gather_stride_rows : D.chunk_rows);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
@@ -404,6 +404,8 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
   DistState& D = h->dist;
   if (!D.configured) { gpx_set_error(h, "gpx_dist_fit_predict: configure first"); return GPX_ERR_STATE; }
   if (D.P > 1 && !D.comm) { gpx_set_error(h, "gpx_dist_fit_predict: no communicator (gpx_dist_comm_init)"); return GPX_ERR_STATE; }
+  // Every collective below runs whenever a communicator exists -- also a single-rank one (tests/test_gpu_dist.py drives
+  // the RCCL calls, their stream ordering and the per-step counts that way on the one-GPU box).
   ncclComm_t comm = (ncclComm_t)D.comm;
   hipStream_t s = h->s_main;
   const int nb = h->nb;
@@ -413,8 +415,8 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
   // broadcast, panel solve and all-gather are already under way -- the collectives' latency (the per-step cost that
   // does not shrink with the rank count) hides behind the bulk update.  Column k+2 goes back to the main stream one
   // step later, so the only wait on the critical path is for the PREVIOUS step's bulk update.
-  static int dist_la = -1;
-  if (dist_la < 0) { const char* e = getenv("GPX_DIST_LOOKAHEAD"); dist_la = e ? atoi(e) : 1; }
+  const char* la_env = getenv("GPX_DIST_LOOKAHEAD");   // read per call (tests switch it)
+  const int dist_la = la_env ? atoi(la_env) : 1;
   hipStream_t t = h->s_trail;
   while ((int64_t)D.ev_s.size() < D.nblk) {
     hipEvent_t a, b;
@@ -424,12 +426,20 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
   }
   for (int64_t k = 0; k < D.nblk; ++k) {
     GPX_RET(gpx_dist_step_diag(h, k));
-    if (D.P > 1) GPX_NCCL_CHECK(h, ncclBroadcast(D.W, D.W, (size_t)nb * nb, ncclDouble, (int)owner_of(D, k), comm, s));
+    if (comm) GPX_NCCL_CHECK(h, ncclBroadcast(D.W, D.W, (size_t)nb * nb, ncclDouble, (int)owner_of(D, k), comm, s));
     GPX_RET(gpx_dist_step_panel(h, k));
-    if (D.P > 1) GPX_NCCL_CHECK(h, ncclAllGather(D.send, D.recv, (size_t)(D.chunk_rows * nb), ncclDouble, comm, s));
-    else GPX_HIP_CHECK(h, hipMemcpyAsync(D.recv, D.send, (size_t)(D.chunk_rows * nb) * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (!dist_la) { GPX_RET(gpx_dist_step_update(h, k)); continue; }
+    // The all-gather moves only what is left below block k: the count is the largest number of panel rows any rank
+    // still holds (every rank computes the same value), not the full-height chunk of step 0 -- half the bytes overall.
+    int64_t step_rows = 0;
+    for (int r = 0; r < D.P; ++r) step_rows = std::max(step_rows, (nloc_of(D, r) - first_slot_after(D, r, k)) * nb);
+    D.gather_stride_rows = step_rows;
+    if (step_rows > 0) {
+      if (comm) GPX_NCCL_CHECK(h, ncclAllGather(D.send, D.recv, (size_t)(step_rows * nb), ncclDouble, comm, s));
+      else GPX_HIP_CHECK(h, hipMemcpyAsync(D.recv, D.send, (size_t)(step_rows * nb) * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    if (!dist_la) { GPX_RET(gpx_dist_step_update(h, k)); D.gather_stride_rows = 0; continue; }
     GPX_RET(gpx_dist_step_gather(h, k));
+    D.gather_stride_rows = 0;
     if (k >= 1) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)(k - 1)], 0));   // column k+1 was last written by the bulk update of step k-1
     GPX_RET(gpx_dist_step_update_cols(h, k, k + 1, 1, 0));
     GPX_HIP_CHECK(h, hipEventRecord(D.ev_s[(size_t)k], s));
@@ -439,7 +449,7 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
   }
   if (dist_la && D.nblk > 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)(D.nblk - 1)], 0));
   GPX_RET(gpx_dist_extract_z(h));
-  if (D.P > 1) GPX_NCCL_CHECK(h, ncclBroadcast(D.z, D.z, (size_t)D.npad, ncclDouble, D.r_owner, comm, s));
+  if (comm) GPX_NCCL_CHECK(h, ncclBroadcast(D.z, D.z, (size_t)D.npad, ncclDouble, D.r_owner, comm, s));
   const int64_t nt = (int64_t)D.test_rows.size();
   std::vector<int64_t> idx((size_t)std::max<int64_t>(nt, 1));
   std::vector<double> ml((size_t)std::max<int64_t>(nt, 1)), vl((size_t)std::max<int64_t>(nt, 1));
@@ -453,7 +463,7 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
   // LAPACK-style info is the FIRST failing pivot over all ranks: min over the positive values, carried
   // as max of the negated value (0 = "no failure" maps to -inf)
   double neg_info = info > 0 ? -(double)info : -1e300;
-  if (D.P > 1) {
+  if (comm) {
     GPX_RET(dist_ensure(h, &D.red, &D.red_cap, 2 * m + 2));
     GPX_HIP_CHECK(h, hipMemcpyAsync(D.red, full.data(), (size_t)(2 * m + 1) * sizeof(double), hipMemcpyHostToDevice, s));
     GPX_HIP_CHECK(h, hipMemcpyAsync(D.red + 2 * m + 1, &neg_info, sizeof(double), hipMemcpyHostToDevice, s));

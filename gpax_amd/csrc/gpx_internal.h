@@ -161,6 +161,7 @@ struct DistState {
   int r_owner = 0; int64_t r_local_row = -1;
   std::vector<std::pair<int64_t, int64_t>> test_rows;   // (local row, test index) of the k_cross rows held here
   void* comm = nullptr;                                  // ncclComm_t
+  int64_t gather_stride_rows = 0;                        // rows per rank in `recv` for the step being gathered (0: chunk_rows)
 };
 void gpx_dist_free(gpx_handle* h);
 

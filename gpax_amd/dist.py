@@ -123,7 +123,9 @@ class DistributedStep:
     factors inside ``gpx_dist_fit_predict``.  ``torch.distributed`` must be initialised (any backend): it
     only carries the 128-byte NCCL unique id."""
 
-    def __init__(self, x, x_new, y_minus_m, device=None, nb=128):
+    def __init__(self, x, x_new, y_minus_m, device=None, nb=128, force_comm=False):
+        """``force_comm``: create the RCCL communicator even at one rank, so that every collective of the driver
+        runs (as a self-copy) -- how the RCCL calls are exercised on a one-GPU box (tests/test_gpu_dist.py)."""
         import torch.distributed as dist
 
         self.rank = dist.get_rank() if dist.is_initialized() else 0
@@ -131,13 +133,14 @@ class DistributedStep:
         self.core = Core(self.rank if device is None else device)
         self.core.set_option("nb", nb)
         self.r = _Rank(self.core, self.rank, self.nranks, x, x_new, y_minus_m)
-        if self.nranks > 1:
+        if self.nranks > 1 or force_comm:
             uid = [None]
             if self.rank == 0:
                 buf = C.create_string_buffer(128)
                 self.core._check(self.core._lib.gpx_dist_unique_id(buf), "gpx_dist_unique_id")
                 uid = [buf.raw]
-            dist.broadcast_object_list(uid, src=0)
+            if self.nranks > 1:
+                dist.broadcast_object_list(uid, src=0)
             self.core._check(self.core._lib.gpx_dist_comm_init(self.core._h, uid[0], self.rank, self.nranks), "gpx_dist_comm_init")
 
     def fit_predict(self, params, m_new=None, new_noise=0.0):

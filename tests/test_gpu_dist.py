@@ -69,3 +69,26 @@ def test_rccl_driver_world_size_1():
     logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, p)
     assert info == 0 and abs(logp - logp_ref) <= 1e-10 * abs(logp_ref)
     assert np.abs(mean - mean_ref).max() <= 1e-8 and np.abs(var - var_ref).max() <= 1e-8
+
+
+@pytest.mark.parametrize("lookahead", ["1", "0"])
+def test_rccl_driver_single_rank_communicator(lookahead, monkeypatch):
+    """The RCCL calls themselves (ncclCommInitRank, ncclBroadcast of W_k and z, the shrinking ncclAllGather of the
+    panel, the two ncclAllReduce of the epilogue) on the driver's streams, through a one-rank communicator: the only
+    way to run them on a one-GPU box.  Same answer as the oracle; N not a multiple of nb, M > nb (two border blocks)."""
+    import gpax_amd
+    from gpax_amd.dist import DistributedStep
+    from oracle import gp_oracle as orc
+
+    monkeypatch.setenv("GPX_DIST_LOOKAHEAD", lookahead)
+    x, y, xn, p = orc.synthetic_problem(1100, 8, 150, seed=11)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    step = DistributedStep(x, xn, y - 1.0, device=0, force_comm=True)
+    try:
+        for _ in range(2):   # the second call reuses the communicator, events and buffers
+            info, logp, mean, var = step.fit_predict(prm, np.ones(150), 0.0)
+    finally:
+        step.close()
+    logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, p)
+    assert info == 0 and abs(logp - logp_ref) <= 1e-10 * abs(logp_ref)
+    assert np.abs(mean - mean_ref).max() <= 1e-8 and np.abs(var - var_ref).max() <= 1e-8
