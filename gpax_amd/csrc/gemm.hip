@@ -59,6 +59,9 @@ __device__ __forceinline__ int64_t tile_global_row(const GemmArgs& g, int64_t m0
 __device__ __forceinline__ bool tile_from_block(const struct GemmArgs& g, int64_t& ti, int64_t& tj);
 
 #define GEMM_BK 32
+#ifndef GEMM_MAIN_WAVES
+#define GEMM_MAIN_WAVES 3   // waves per SIMD the register budget of gemm_nt_kernel is sized for (168 VGPRs: three workgroups per CU)
+#endif
 #define GEMM_LDT (GEMM_BK + 4)
 
 // Diagnostic build only (make TIMELINE=1 -> libgpx_hip_tl.so, tools/timeline2.py): the first thread of every
@@ -114,11 +117,11 @@ __device__ __forceinline__ bool tile_from_block(const GemmArgs& g, int64_t& ti, 
   return ti < g.map_nti && tj < g.map_ntj && tj <= ti;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool HASC>   // HASC: beta != 0 (compile-time, so that the C requests are straight-line code)
 // (256, 2): a register budget of 256 makes hipcc keep the accumulators in VGPRs.  With the default budget it
 // puts them in AGPRs, and v_mfma_f64_16x16x4_f64 with an AGPR accumulator issues every ~100 cycles instead of
 // 64 (tools/peaks: 49 vs 78 TFLOP/s) -- the single largest factor in this kernel's throughput.
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs g) {
   constexpr int TM = BM / 32, TN = BN / 32;        // 16x16 MFMA tiles per wave (waves as 2 x 2)
   constexpr int NA = BM * (GEMM_BK / 2) / 256;      // 16-B chunks per thread, A tile
   constexpr int NBc = BN * (GEMM_BK / 2) / 256;
@@ -200,12 +203,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 
   const int64_t kbeg = g.a_upper_tri ? (m0 / GEMM_BK) * GEMM_BK : 0;
   GEMM_STAMP(0);
-  load_tiles(kbeg);
-  // The C tile (an HBM miss: it is streamed, read once per launch) is requested AFTER the first A/B chunk
-  // (L2 hits) and consumed only in the epilogue.  Loads return in order, so the first LDS store waits for the
-  // A/B chunk alone and the C latency hides behind the first chunk's MFMAs instead of in front of them
-  // (stamps: the first chunk took 7-8k cycles against 2.5k for the others when C initialised the accumulators).
-  if (g.beta != 0.0) {
+  // The C tile is streamed (read once per launch, from HBM or the Infinity Cache: ~2 us under load) and consumed only
+  // in the epilogue.  Loads return IN ORDER, so whatever is requested before an operand chunk has to arrive before
+  // that chunk can be used: requested up front (behind the first chunk), the C tile is waited for at the second
+  // chunk and only the first chunk's MFMAs (0.85 us) cover its latency.  It is therefore requested LAST -- behind the
+  // operands of the last chunk, while the second-to-last chunk is still to be multiplied -- so that two chunks of
+  // MFMAs cover it and no operand load queues behind it.  (The code is peeled so that this is straight-line: inside
+  // a loop with a condition the compiler's wait-count pass falls back to vmcnt(0) before the last chunk's LDS store.)
+  auto load_c = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -214,8 +219,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) cin[i][j][r] = cp[(int64_t)(4 * r) * g.ldc];
       }
-  }
-  for (int64_t k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+  };
+  auto chunk = [&](int64_t k0, const bool prefetch, const bool request_c, const bool last) __attribute__((always_inline)) {
 #if defined(GPX_ABLATE) && (GPX_ABLATE & 2)
     if (k0 == kbeg)
 #endif
@@ -225,8 +230,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     GEMM_STAMP(2 + 3 * (int)(k0 / GEMM_BK));
 #if defined(GPX_ABLATE) && (GPX_ABLATE & 1)
 #else
-    if (k0 + GEMM_BK < kend) load_tiles(k0 + GEMM_BK);  // in flight during the MFMAs below
+    if (prefetch) load_tiles(k0 + GEMM_BK);  // in flight during the MFMAs below
 #endif
+    if (request_c) load_c();
 #pragma unroll
     for (int s = 0; s < GEMM_BK / 8; ++s) {
       v2d a[TM], b[TN];
@@ -253,7 +259,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
     GEMM_STAMP(3 + 3 * (int)(k0 / GEMM_BK));
 #if defined(GPX_ABLATE) && (GPX_ABLATE & 4)
 #else
-    __syncthreads();
+    if (!last) __syncthreads();
+#endif
+  };
+  load_tiles(kbeg);
+  if (kbeg + GEMM_BK >= kend) {          // a single chunk
+    if (HASC) load_c();
+    chunk(kbeg, false, false, true);
+  } else {
+    int64_t k0 = kbeg;
+#ifdef GEMM_EARLY_C
+    if (HASC) load_c();
+    for (; k0 + GEMM_BK < kend; k0 += GEMM_BK) chunk(k0, true, false, false);
+    chunk(k0, false, false, true);
+#else
+    for (; k0 + 2 * GEMM_BK < kend; k0 += GEMM_BK) chunk(k0, true, false, false);
+    chunk(k0, true, HASC, false);         // second to last
+    chunk(k0 + GEMM_BK, false, false, true);
 #endif
   }
   GEMM_STAMP(13);
@@ -268,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
       for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + wm * (BM / 2) + i * 16 + fk + 4 * r;
         // (non-temporal and agent-scope write-through stores were A/B-tested here: no effect on the step time)
-        g.C[row * g.ldc + col] = fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]);
+        g.C[row * g.ldc + col] = HASC ? fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]) : g.alpha * acc[i][j][r];
       }
     }
 }
@@ -281,7 +303,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 // chunk -- of the same tile or of the next one -- and the next tile's C tile is fetched two
 // stages ahead into spare registers; the store of tile t overlaps the first chunk of tile t+1.
 // Tiles are enumerated over the lower trapezoid only (no empty workgroups).
-__global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(GemmArgs g, int ntj, int64_t ntiles) {
+#ifndef GEMM_PERSIST_WAVES
+#define GEMM_PERSIST_WAVES 2
+#endif
+__global__ __launch_bounds__(256, GEMM_PERSIST_WAVES) void gemm_nt_persist_kernel(GemmArgs g, int ntj, int64_t ntiles) {
   constexpr int BM = 64, BN = 64, TM = 2, TN = 2;
   constexpr int NA = BM * (GEMM_BK / 2) / 256, NBc = BN * (GEMM_BK / 2) / 256;
   __shared__ __attribute__((aligned(16))) double As[BM * GEMM_LDT];
@@ -400,6 +425,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_persist_kernel(GemmArgs g, int
     m0 = m1; n0 = n1;
   }
 }
+
+// (A 128x128-tile kernel -- 64x64 per wave, 128 accumulator VGPRs, accumulators initialised from C, K in chunks of 16
+// through a double-buffered LDS image, two workgroups per CU -- halves the operand bytes per flop but measured slower
+// than the 64x64 kernel at every shape: 38 vs 44 TFLOP/s at M=4736 N=3712 K=128, 60.5 vs 65.9 at 24576^2 K=512.  With
+// eight waves per CU the per-tile C latency is exposed; the 64x64 kernel's three workgroups per CU cover it.  Removed.)
 
 // ---- latency variant for K = nb (64 or 128): one pass, one barrier ---------------------------
 // The panel solve and the look-ahead update sit on the critical path of the factorisation and
@@ -534,16 +564,9 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   if (!L.small_tile && L.variant == 1 && L.cyc_P <= 1 && L.lower && L.beta != 0.0 && L.row_off == L.col_off && L.M >= L.N && L.K >= 2 * GEMM_BK) {
     const int64_t ntj = L.N / 64, nti = L.M / 64;
     const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
-    const int64_t slots = 256 * 3;   // CUs x resident workgroups (140 VGPRs -> 3 waves/SIMD)
+    const int64_t slots = 256 * (GEMM_PERSIST_WAVES > 3 ? GEMM_PERSIST_WAVES : 3);   // CUs x resident workgroups
     dim3 pg((unsigned)(ntiles < slots ? ntiles : slots));
     hipLaunchKernelGGL(gemm_nt_persist_kernel, pg, dim3(256), 0, s, g, (int)ntj, ntiles);
-    GPX_HIP_CHECK(h, hipGetLastError());
-    if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
-    return GPX_OK;
-  }
-  if (!L.small_tile && L.variant == 2 && L.M % 128 == 0 && L.N % 128 == 0) {
-    dim3 g128((unsigned)(L.N / 128), (unsigned)(L.M / 128));
-    hipLaunchKernelGGL((gemm_nt_kernel<128, 128>), g128, dim3(256), 0, s, g);
     GPX_HIP_CHECK(h, hipGetLastError());
     if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
@@ -552,7 +575,8 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     const int64_t nti = L.M / 64, ntj = L.N / 64;
     g.map_S = -1; g.map_nti = nti; g.map_ntj = ntj;
     const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
-    hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
     GPX_HIP_CHECK(h, hipGetLastError());
     return GPX_OK;
   }
@@ -571,7 +595,8 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     const int64_t nsi = (nti + S - 1) / S;
     g.map_nsuper = g.map_nsj * (g.map_nsj + 1) / 2 + (nsi - g.map_nsj) * g.map_nsj;
     const int64_t rounds = (g.map_nsuper + 7) / 8;
-    hipLaunchKernelGGL((gemm_nt_kernel<64, 64>), dim3((unsigned)(rounds * 8 * S * S)), dim3(256), 0, s, g);
+    if (L.beta != 0.0) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3((unsigned)(rounds * 8 * S * S)), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), dim3((unsigned)(rounds * 8 * S * S)), dim3(256), 0, s, g);
     GPX_HIP_CHECK(h, hipGetLastError());
     if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
@@ -579,8 +604,10 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   hipEvent_t se = L.stop_event, sb = L.start_event;
   if (L.small_tile && L.K == 128) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<128>), grid, dim3(256), 0, s, sb, se, 0, g);
   else if (L.small_tile && L.K == 64) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, sb, se, 0, g);
-  else if (L.small_tile) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32>), grid, dim3(256), 0, s, sb, se, 0, g);
-  else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else if (L.small_tile && L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32, true>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else if (L.small_tile) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32, false>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), grid, dim3(256), 0, s, sb, se, 0, g);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
