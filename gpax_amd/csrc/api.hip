@@ -202,14 +202,23 @@ static int upload_small(gpx_handle* h, hipStream_t s, double* dst, const double*
 }
 
 #ifdef GPX_TIMELINE
-void tl_set_gemm(unsigned long long* p);
+void tl_set_gemm(unsigned long long* p, unsigned long long* ends);
 void tl_set_potrf(unsigned long long* p);
 static unsigned long long* g_tl_dev = nullptr;
+static unsigned long long* g_tl_ends = nullptr;
 extern "C" int gpx_timeline_start(void) {
   if (!g_tl_dev && hipMalloc(reinterpret_cast<void**>(&g_tl_dev), (4 + 4 * 16000) * 8) != hipSuccess) return -1;
+  if (!g_tl_ends && hipMalloc(reinterpret_cast<void**>(&g_tl_ends), 8192 * 8) != hipSuccess) return -1;
   (void)hipMemset(g_tl_dev, 0, (4 + 4 * 16000) * 8);
-  tl_set_gemm(g_tl_dev); tl_set_potrf(g_tl_dev);
+  (void)hipMemset(g_tl_ends, 0, 8192 * 8);
+  tl_set_gemm(g_tl_dev, g_tl_ends); tl_set_potrf(g_tl_dev);
   return 0;
+}
+extern "C" long long gpx_timeline_read_ends(unsigned long long* out, long long max_records) {
+  (void)hipDeviceSynchronize();
+  const long long n = max_records < 8192 ? max_records : 8192;
+  (void)hipMemcpy(out, g_tl_ends, (size_t)n * 8, hipMemcpyDeviceToHost);
+  return n;
 }
 extern "C" long long gpx_timeline_read(unsigned long long* out, long long max_records) {
   unsigned long long n = 0;
@@ -297,6 +306,8 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_DEPTH"))) h->depth = std::min(std::max(atoi(env), 1), 3);
   if ((env = getenv("GPX_PAIR_MIN"))) h->pair_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
+  if ((env = getenv("GPX_LA_ROWS"))) h->la_rows = std::max(atoi(env), 0);
+  if ((env = getenv("GPX_COL_SPLIT"))) h->col_split = std::max(atoi(env), 0);
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -368,6 +379,8 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "depth")) { h->depth = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 3); return GPX_OK; }
   if (!strcmp(name, "pair_min")) { h->pair_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
+  if (!strcmp(name, "la_rows")) { h->la_rows = (int)std::max<int64_t>(value, 0); return GPX_OK; }
+  if (!strcmp(name, "col_split")) { h->col_split = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -382,6 +395,8 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "depth")) { *value = h->depth; return GPX_OK; }
   if (!strcmp(name, "pair_min")) { *value = h->pair_min; return GPX_OK; }
   if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
+  if (!strcmp(name, "la_rows")) { *value = h->la_rows; return GPX_OK; }
+  if (!strcmp(name, "col_split")) { *value = h->col_split; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -908,7 +923,10 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       t.B = L + cfirst * nb * ld + kfirst * nb; t.ldb = ld;
       t.C = A + rr * ld + cfirst * nb; t.ldc = ld;
       t.M = mr; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-      t.lower = 1; t.row_off = rr; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 1;
+      t.lower = 1; t.row_off = rr; t.col_off = cfirst * nb; t.b_lower_tri = 0;
+      // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
+      // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency
+      t.small_tile = (h->la_rows > 0 && mr >= h->la_rows) ? 0 : 1;
       double entries = 0.0;
       for (int64_t c = cfirst; c < cfirst + ncol; ++c)
         entries += (c * nb >= rr) ? (double)nb * (nb + 1) / 2.0 + (double)(mr - nb) * nb : (double)mr * nb;
@@ -919,15 +937,25 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     };
     const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
     if (mr > 0) {
-      if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {   // column k+2 was last written by T there
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
-        q_waited_t = last_t;
-      }
+      auto wait_for_t = [&]() -> int {   // column k+2 was last written by T at step last_t
+        if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {
+          GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
+          q_waited_t = last_t;
+        }
+        return GPX_OK;
+      };
       const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
-      if (npan2 > 1 && ncb > 1) {
+      // While the factorisation is bulk-bound the two columns go separately: column k+1 (whose last bulk update
+      // Q waited for a step ago) needs no bulk update to finish, only column k+2 does.  As one two-column kernel
+      // behind the wait, the update -- slowed 3-4x by the bulk kernel it shares the CUs with -- and the next panel
+      // behind it took longer than one bulk update, and the bulk stream idled ~18 us per step at N = 4096.
+      const bool split = ncb > 1 && (npan2 > 1 || (h->col_split > 0 && nblk - (k + 3) >= h->col_split));
+      if (split) {
         GPX_RET(col_update(k + 1, 1, k, 1, false));
+        GPX_RET(wait_for_t());
         GPX_RET(col_update(k + 2, 1, last_t + 1, npan2, true));
       } else {
+        GPX_RET(wait_for_t());
         GPX_RET(col_update(k + 1, ncb, k, 1, true));
       }
     }

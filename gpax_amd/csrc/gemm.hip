@@ -39,6 +39,7 @@ struct GemmArgs {
   unsigned* signal;   // one-pass path: publish the stored tile to an already-resident consumer (see GemmLaunch::signal)
   const unsigned* wait_flag; unsigned wait_count;   // one-pass path: resident start (see GemmLaunch::wait_flag)
   int* wait_info;     // set to -7 when the bounded wait gives up
+  int tl_id;          // diagnostic timeline build only: launch number (index of this launch's end-time cell)
 };
 
 // first global row of the tile whose first (local) row is row_off + m0
@@ -68,19 +69,32 @@ __device__ __forceinline__ bool tile_from_block(const struct GemmArgs& g, int64_
 // kernel logs (kind, s_memrealtime, M, N) into a device buffer -- an unperturbed timeline of kernel STARTS.
 #ifdef GPX_TIMELINE
 __device__ unsigned long long* g_tl_gemm;
-void tl_set_gemm(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_gemm), &p, sizeof(p)); }
+__device__ unsigned long long* g_tl_gemm_end;   // [launch number] = latest time any workgroup of that launch passed GEMM_TL_END
+static int g_tl_launch = 0;
+void tl_set_gemm(unsigned long long* p, unsigned long long* ends) {
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_gemm), &p, sizeof(p));
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_gemm_end), &ends, sizeof(ends));
+  g_tl_launch = 0;
+}
 #define GEMM_TL(kind, a, b)                                                                                  \
   do {                                                                                                       \
     if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && g_tl_gemm) {                               \
       const unsigned long long slot = atomicAdd(g_tl_gemm, 1ull);                                            \
       if (slot < 16000) {                                                                                    \
         unsigned long long* r = g_tl_gemm + 4 + 4 * slot;                                                    \
-        r[0] = (kind); r[1] = __builtin_amdgcn_s_memrealtime(); r[2] = (unsigned long long)(a); r[3] = (unsigned long long)(b); \
+        r[0] = (unsigned long long)(kind) | ((unsigned long long)(g.tl_id + 1) << 8); r[1] = __builtin_amdgcn_s_memrealtime(); \
+        r[2] = (unsigned long long)(a); r[3] = (unsigned long long)(b);                                      \
       }                                                                                                      \
     }                                                                                                        \
   } while (0)
+#define GEMM_TL_END()                                                                                        \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && g_tl_gemm_end && g.tl_id >= 0 && g.tl_id < 8192)                                 \
+      atomicMax(&g_tl_gemm_end[g.tl_id], (unsigned long long)__builtin_amdgcn_s_memrealtime());              \
+  } while (0)
 #else
 #define GEMM_TL(kind, a, b) do { } while (0)
+#define GEMM_TL_END() do { } while (0)
 #endif
 
 // Diagnostic build only (tools/gemm_bench): s_memtime stamps of one workgroup's phases.
@@ -88,7 +102,7 @@ void tl_set_gemm(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_t
 __device__ unsigned long long* g_gemm_stamps;
 #define GEMM_STAMP(slot)                                                                         \
   do {                                                                                           \
-    if (threadIdx.x == 0 && blockIdx.x == 1 && blockIdx.y == gridDim.y - 2) g_gemm_stamps[slot] = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0) g_gemm_stamps[slot] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
 #define GEMM_STAMP(slot) do { } while (0)
@@ -217,6 +231,8 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
       for (int j = 0; j < TN; ++j) {
         const double* cp = g.C + (m0 + wm * (BM / 2) + i * 16 + fk) * g.ldc + n0 + wn * (BN / 2) + j * 16 + fr;
 #pragma unroll
+        // (non-temporal C loads: 71 -> 61 us standalone on some boxes, but 1.765 -> 1.81 ms per N = 4096 step in situ --
+        // the next kernels re-read these tiles from the caches -- so the default policy stays)
         for (int r = 0; r < 4; ++r) cin[i][j][r] = cp[(int64_t)(4 * r) * g.ldc];
       }
   };
@@ -293,6 +309,8 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
         g.C[row * g.ldc + col] = HASC ? fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]) : g.alpha * acc[i][j][r];
       }
     }
+  GEMM_STAMP(14);
+  GEMM_TL_END();
 }
 
 // ---- persistent, tile-pipelined variant of the 64x64 kernel (the trailing update) ------------
@@ -518,6 +536,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    GEMM_TL_END();
     return;
   }
 #pragma unroll
@@ -526,6 +545,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
     if (g.beta != 0.0) v += g.beta * cin[r];
     cp[(int64_t)(4 * r) * g.ldc] = v;
   }
+  GEMM_TL_END();
 }
 
 // GPX_TILE_MAP: 0 (default) 1-D row-major enumeration of the lower trapezoid, 1 XCD-aware super-tiles, 2 plain 2-D grid
@@ -551,6 +571,11 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   g.a_upper_tri = L.a_upper_tri;
   g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
   g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
+#ifdef GPX_TIMELINE
+  g.tl_id = g_tl_launch++;
+#else
+  g.tl_id = -1;
+#endif
   if ((L.signal || L.wait_flag) && !(L.small_tile && (L.K == 128 || L.K == 64))) {
     gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel only");
     return GPX_ERR_ARG;
