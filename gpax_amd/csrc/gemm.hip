@@ -444,6 +444,11 @@ __global__ __launch_bounds__(256, GEMM_PERSIST_WAVES) void gemm_nt_persist_kerne
   }
 }
 
+// (A streaming variant -- 768 resident workgroups taking tiles from a device counter, the next tile's first operand
+// chunk requested during the last chunk of the current one so that only a workgroup's first tile starts cold -- was
+// written and measured: 41.9 vs 46.1 TFLOP/s at M=4736 N=3712 K=128, 1.91 vs 1.76 ms per N = 4096 step.  Like the
+// tile-pipelined kernel below and the 128x128 tiles, it loses to plain one-tile workgroups: the hardware dispatcher
+// de-correlates the phases of the three workgroups of a CU, resident workgroups stay in lock-step.  Removed.)
 // (A 128x128-tile kernel -- 64x64 per wave, 128 accumulator VGPRs, accumulators initialised from C, K in chunks of 16
 // through a double-buffered LDS image, two workgroups per CU -- halves the operand bytes per flop but measured slower
 // than the 64x64 kernel at every shape: 38 vs 44 TFLOP/s at M=4736 N=3712 K=128, 60.5 vs 65.9 at 24576^2 K=512.  With

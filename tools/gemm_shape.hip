@@ -11,6 +11,7 @@ int main(int argc, char** argv) {
   double *A, *L; CK(hipMalloc(&A, M * ld * 8)); CK(hipMalloc(&L, M * ld * 8));
   CK(hipMemset(A, 0, M * ld * 8)); CK(hipMemset(L, 0, M * ld * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+
   for (int a = 3; a < argc; ++a) {
     const int64_t K = atoll(argv[a]);
     GemmLaunch t;
@@ -21,9 +22,10 @@ int main(int argc, char** argv) {
     if (getenv("RECT")) {   // RECT=1: full M x N rectangle on the 64x64 kernel, RECT=2: on the one-pass 32x32 kernel (the look-ahead column updates)
       t.lower = 0; entries = (double)M * N; t.small_tile = atoi(getenv("RECT")) == 2;
     }
-    for (int w = 0; w < 2; ++w) launch_gemm_nt(nullptr, 0, t);
+    auto go = [&]() { launch_gemm_nt(nullptr, 0, t); };
+    for (int w = 0; w < 2; ++w) go();
     CK(hipDeviceSynchronize());
-    CK(hipEventRecord(e0)); for (int r = 0; r < 5; ++r) launch_gemm_nt(nullptr, 0, t); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventRecord(e0)); for (int r = 0; r < 5; ++r) go(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
     printf("M=%lld N=%lld K=%lld: %.1f us  %.1f TFLOP/s\n", (long long)M, (long long)N, (long long)K, ms * 1e3, 2.0 * entries * K / ms * 1e-9);
   }
