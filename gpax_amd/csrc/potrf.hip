@@ -420,6 +420,9 @@ void tl_set_potrf(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #define POTRF_TL(kind, a) do { } while (0)
 #endif
 
+#ifndef POTRF_WAVES_128
+#define POTRF_WAVES_128 8   // waves of the 128-wide kernel.  12 / 16 waves spread the shadow work thinner but spill (168 / 128-register budgets) and crowd the leaf wave's SIMD: 1.77 -> 1.94 / 2.13 ms per N = 4096 step
+#endif
 template <int NB, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A,
                                                                  int64_t lda, double* __restrict__ L,
@@ -602,7 +605,7 @@ int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int
       hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag);
       break;
     case 128:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), dim3(1), dim3(512), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<128, POTRF_WAVES_128>), dim3(1), dim3(64 * POTRF_WAVES_128), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");
