@@ -308,6 +308,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
   if ((env = getenv("GPX_LA_ROWS"))) h->la_rows = std::max(atoi(env), 0);
   if ((env = getenv("GPX_COL_SPLIT"))) h->col_split = std::max(atoi(env), 0);
+  if ((env = getenv("GPX_NEAR_BLOCK"))) h->near_block = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -381,6 +382,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "la_rows")) { h->la_rows = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "col_split")) { h->col_split = (int)std::max<int64_t>(value, 0); return GPX_OK; }
+  if (!strcmp(name, "near_block")) { h->near_block = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -397,6 +399,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
   if (!strcmp(name, "la_rows")) { *value = h->la_rows; return GPX_OK; }
   if (!strcmp(name, "col_split")) { *value = h->col_split; return GPX_OK; }
+  if (!strcmp(name, "near_block")) { *value = h->near_block; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -845,9 +848,14 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
   // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
   const int64_t pair_min = kinv ? std::min<int64_t>(h->pair_min, 8) : h->pair_min, quad_min = h->quad_min;
-  int64_t last_t = -1;        // last step at which T acted (panels <= last_t are in every column >= last_t+3)
+  int64_t last_t = -1;        // last group end (panels <= last_t are in every column >= last_t+3: by Q's near block and T's bulk launch)
   int64_t group_end = -1;     // the step at which T acts next
-  int64_t q_waited_t = -1;    // the T step Q has already waited for
+  int64_t q_waited_t = -1;    // the T launch (its step) Q has already waited for
+  int64_t t_idx = -1;         // step of the most recent bulk launch on T (its hand-over event is ev_trail[t_idx])
+  int64_t t_from = nblk;      // first block column that launch wrote: Q waits for it only before touching a column >= t_from
+  auto group_size = [&](int64_t left) -> int64_t {
+    return (quad_min > 0 && left > quad_min) ? 4 : ((pair_min > 0 && left > pair_min) ? 2 : 1);
+  };
   int64_t kinv_last = -1;     // last panel folded into K^-1 (gradient path)
   static int kinv_group_env = -1;
   if (kinv_group_env < 0) { const char* e = getenv("GPX_KINV_GROUP"); kinv_group_env = e ? atoi(e) : 2; }
@@ -855,14 +863,23 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   std::vector<char> t_pending((size_t)nblk, 0);
   auto side = [&](int64_t k) -> int {
     if (k > group_end) {
-      const int64_t left = nblk - k;
-      const int64_t g = (quad_min > 0 && left > quad_min) ? 4 : ((pair_min > 0 && left > pair_min) ? 2 : 1);
-      group_end = k + g - 1;
+      group_end = k + group_size(nblk - k) - 1;
     }
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
     const int64_t mrows = rows - r0;
     if (mrows <= 0) return GPX_OK;
     if (k + 1 >= nblk && !kinv) return GPX_OK;   // the last panel (border rows only) is launched by the chain itself
+    // Grouped phases: the bulk launch at a group end leaves the NEXT group's columns (the "near block", as many block
+    // columns as that group has panels) to Q, which applies the same panels to them in one K = g nb launch of its own.
+    // The chain of the next group then depends on that short launch only and runs WHILE the bulk launch does; with
+    // the bulk launch covering everything from column k+3 the chain stalled at the first step of every group until
+    // the bulk launch had finished and the bulk stream then idled for the 2-4 chain steps that produce its next
+    // panels (N = 16384: ~270 us of every ~2.3 ms).
+    int64_t near_cols = 0;
+    if (k == group_end && h->near_block && !kinv) {
+      const int64_t g_next = group_size(nblk - (k + 1));
+      if (g_next >= 2) near_cols = std::max<int64_t>(0, std::min<int64_t>(g_next, nblk - (k + 3)));
+    }
     if (!await(w_rec[(size_t)k])) return GPX_ERR_HIP;
     // (Starting the panel kernel resident too -- it would sleep on potrf_diag's flag instead of waiting ~8 us for the
     // cross-stream event -- crowds the bulk update with sleeping workgroups: 1.76 -> 1.81 ms, not used.)
@@ -876,7 +893,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
       // T gets its own event on the panel: the bulk update must not wait for the column kernels below (with one
       // shared event after them the N = 4096 step went from 1.90 to 2.17 ms: every bulk update starts late)
-      const bool t_needs = (k + 1 < nblk && k == group_end && nblk - (k + 3) > 0) || (kinv && (k == group_end || k + 1 >= nblk));
+      const bool t_needs = (k + 1 < nblk && k == group_end && nblk - (k + 3 + near_cols) > 0) || (kinv && (k == group_end || k + 1 >= nblk));
       if (t_needs && attach) g.stop_event = h->ev_panel[(size_t)k];
       prof_begin(h, Q, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
       GPX_RET(launch_gemm_nt(h, Q, g));
@@ -937,10 +954,10 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     };
     const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
     if (mr > 0) {
-      auto wait_for_t = [&]() -> int {   // column k+2 was last written by T at step last_t
-        if (last_t >= 0 && last_t != q_waited_t && t_pending[(size_t)last_t]) {
-          GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)last_t], 0));
-          q_waited_t = last_t;
+      auto wait_for_t = [&]() -> int {   // column k+2 was last written by the bulk launch of step t_idx -- if it lies in its range
+        if (t_idx >= 0 && k + 2 >= t_from && t_idx != q_waited_t && t_pending[(size_t)t_idx]) {
+          GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)t_idx], 0));
+          q_waited_t = t_idx;
         }
         return GPX_OK;
       };
@@ -962,13 +979,32 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
     far_rec[(size_t)k].store(1, std::memory_order_release);
 
-    // T: bulk, columns >= k+3, panels last_t+1 .. k in one pass
-    const int64_t nbulk = nblk - (k + 3);
+    // Q: the near block (columns k+3 .. k+2+near_cols, panels last_t+1 .. k), behind the event the chain waits for
+    if (near_cols > 0) {
+      if (t_idx >= 0 && t_idx != q_waited_t && t_pending[(size_t)t_idx]) {   // those columns were last written by the previous bulk launch
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)t_idx], 0));
+        q_waited_t = t_idx;
+      }
+      const int64_t kfirst = last_t + 1, npan = k - last_t;
+      const int64_t br = (k + 3) * nb, bm = rows - br, nc = near_cols * nb;
+      GemmLaunch t;
+      t.A = L + br * ld + kfirst * nb; t.lda = ld;
+      t.B = L + br * ld + kfirst * nb; t.ldb = ld;
+      t.C = A + br * ld + br; t.ldc = ld;
+      t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
+      t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
+      const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
+      prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
+      GPX_RET(launch_gemm_nt(h, Q, t));
+      prof_end(h, Q);
+    }
+    // T: bulk, columns >= k+3 (+ the near block), panels last_t+1 .. k in one pass
+    const int64_t nbulk = nblk - (k + 3 + near_cols);
     if (k == group_end) {
       if (nbulk > 0) {
         GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
         const int64_t kfirst = last_t + 1, npan = k - last_t;
-        const int64_t cf = k + 3, br = cf * nb, bm = rows - br, nc = nbulk * nb;
+        const int64_t cf = k + 3 + near_cols, br = cf * nb, bm = rows - br, nc = nbulk * nb;
         GemmLaunch t;
         t.A = L + br * ld + kfirst * nb; t.lda = ld;
         t.B = L + br * ld + kfirst * nb; t.ldb = ld;
@@ -983,6 +1019,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         GPX_RET(launch_gemm_nt(h, T, t));
         if (!attach || timed) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
         t_pending[(size_t)k] = 1;
+        t_idx = k; t_from = cf;
       }
       // behind the bulk update (Q's next column update waits for that one, not for this), two panels at a time:
       // nothing waits for K^-1 before the end and K = 2 nb passes run at 48 instead of 40 TFLOP/s (groups of 4 or 8

@@ -207,8 +207,9 @@ struct gpx_handle {
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 32;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 48;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int near_block = 1;  // grouped phases: the next group's columns are updated by Q in a launch of its own, the bulk launch starts behind them
   int col_split = 0;   // the two look-ahead columns are updated by separate kernels while at least this many block columns are left to the bulk update; 0 = never
-  int la_rows = 0;     // look-ahead column updates use 64x64 tiles while at least this many rows remain below; 0 = never
+  int la_rows = 4096;  // look-ahead column updates use 64x64 tiles while at least this many rows remain below (-1 % at N = 8192/16384); 0 = never
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
   // resident inputs

@@ -21,13 +21,16 @@ int gpx_dist_configure(gpx_handle* h, int rank, int nranks, const double* x, int
 int gpx_dist_set_targets(gpx_handle* h, const double* y_minus_m);
 int gpx_dist_info(gpx_handle* h, int64_t* nsteps, int64_t* nloc_rows, int* r_owner, int64_t* n_test_local);
 
-/* RCCL communicator: rank 0 creates the id, every rank calls comm_init with it. */
+/* RCCL communicator: rank 0 creates the id, every rank calls comm_init with it.  A communicator of ONE rank is
+ * allowed: gpx_dist_fit_predict issues every collective whenever a communicator exists (that is how the RCCL
+ * calls are exercised on a one-GPU box). */
 int gpx_dist_unique_id(char* out128);
 int gpx_dist_comm_init(gpx_handle* h, const char* uid128, int rank, int nranks);
 int gpx_dist_comm_destroy(gpx_handle* h);
 
 /* Whole distributed fit+predict step (gram of own block rows, factorisation with RCCL broadcast /
- * all-gather per panel, log-marginal, posterior mean / variance); outputs complete on every rank. */
+ * all-gather per panel, log-marginal, posterior mean / variance); outputs complete on every rank.
+ * The all-gather of step k moves max_r(rows rank r still holds below block k) x nb doubles per rank. */
 int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, const double* m_new, double new_noise,
                          double* logp, double* mean_out, double* var_out);
 
