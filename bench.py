@@ -116,54 +116,68 @@ def bench_distributed(args, rank, local_rank, world, dist, torch):
         dist.destroy_process_group()
 
 
-def dist_leg(args, rank, local_rank, world, dist, torch):
+def dist_leg(args, rank, local_rank, world, dist, torch, out):
     """Config C4 beside the headline number, at world size > 1 only: ONE N x N factorisation (default N=32768, d=8,
     M=1000) distributed row-block-cyclic over the ranks, RCCL broadcast of inv(L_kk) + all-gather of the panel per
     step (gpax_amd/csrc/dist.hip) -- strong scaling, timed like the main region (barrier, K steps, barrier, MAX over
-    ranks).  Rank 0 then runs the same problem through the single-GPU path and reports the difference."""
+    ranks).  Two schedules of the same driver are timed one after the other: the default one and the early-diagonal
+    one (the owner factorises block k+1 beside the all-gather of panel k).  Rank 0 then runs the same problem through
+    the single-GPU path and reports the difference.  Results are written into out["dist_c4"] as they come, so that a
+    watchdog print still carries what was finished."""
     import gpax_amd
     from gpax_amd.dist import DistributedStep
 
     n, d, m = args.dist_n, args.d, args.m
     x, y, x_new = synthetic_problem(n, d, m, seed=0)
     params = gpax_amd.make_params(gpax_amd.RBF, 1.0, 1.0, None, np.array([0.006744897501960818]), 1e-6, True)
-    step = DistributedStep(x, x_new, y - 1.0, device=local_rank)
-    for _ in range(1):
-        step.fit_predict(params, np.ones(m), 0.0)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.dist_steps):
-        info, logp, mean, var = step.fit_predict(params, np.ones(m), 0.0)
-    torch.cuda.synchronize()
-    dist.barrier()
-    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    step.close()
-    ms = elapsed / args.dist_steps * 1e3
-    res = {
+    res = out["dist_c4"] = {
         "workload": f"ExactGP RBF d={d}, N={n} / M={m}: ONE factorisation, row-block-cyclic over {world} GPUs, RCCL broadcast of "
                     "inv(L_kk) + all-gather of the panel column per step (BASELINE config C4)",
-        "scaling": "strong", "n": n, "steps": args.dist_steps, "ms_per_step": ms, "points_per_s": n / (ms * 1e-3),
-        "step_tflops": (n ** 3 / 3 + n * n * (m + 1)) / (ms * 1e-3) * 1e-12, "info": int(info), "logp": float(logp),
+        "scaling": "strong", "n": n, "steps": args.dist_steps,
     }
+    step = DistributedStep(x, x_new, y - 1.0, device=local_rank, force_comm=args.dist_rehearsal)
+
+    def timed(early):
+        os.environ["GPX_DIST_EARLY_DIAG"] = "1" if early else "0"
+        for _ in range(2):
+            step.fit_predict(params, np.ones(m), 0.0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.dist_steps):
+            r = step.fit_predict(params, np.ones(m), 0.0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ms = float(t.item()) / args.dist_steps * 1e3
+        return ms, r
+
+    flops = n ** 3 / 3 + n * n * (m + 1)
+    ms, (info, logp, mean, var) = timed(False)
+    res.update({"ms_per_step": ms, "points_per_s": n / (ms * 1e-3), "step_tflops": flops / (ms * 1e-3) * 1e-12,
+                "info": int(info), "logp": float(logp)})
+    ms_e, (info_e, logp_e, mean_e, var_e) = timed(True)
+    res["early_diag"] = {"ms_per_step": ms_e, "points_per_s": n / (ms_e * 1e-3), "info": int(info_e), "logp": float(logp_e),
+                         "mean_maxabs_vs_default": float(np.abs(mean_e - mean).max())}
+    step.close()
     if rank == 0:   # the same problem on ONE GPU (single-GPU split-panel schedule): time and agreement
         one = gpax_amd.Core(local_rank)
         one.set_train(x)
         one.set_test(x_new)
         one.set_targets(y - 1.0, np.ones(m))
-        one.fit_predict_async(params, 0.0)
-        one.fetch_results()
+        for _ in range(2):
+            one.fit_predict_async(params, 0.0)
+            one.fetch_results()
         t1 = time.perf_counter()
-        one.fit_predict_async(params, 0.0)
-        info1, logp1, mean1, var1 = one.fetch_results()
-        res["single_gpu_ms_per_step"] = (time.perf_counter() - t1) * 1e3
+        for _ in range(args.dist_steps):
+            one.fit_predict_async(params, 0.0)
+            info1, logp1, mean1, var1 = one.fetch_results()
+        res["single_gpu_ms_per_step"] = (time.perf_counter() - t1) / args.dist_steps * 1e3
         one.close()
         res["vs_single_gpu"] = {"logp_rel": abs(logp - logp1) / abs(logp1), "mean_maxabs": float(np.abs(mean - mean1).max()),
                                 "var_maxabs": float(np.abs(var - var1).max())}
-        res["speedup_vs_single_gpu"] = res["single_gpu_ms_per_step"] / ms
-    return res
+        res["speedup_vs_single_gpu"] = res["single_gpu_ms_per_step"] / min(ms, ms_e)
 
 
 def main():
@@ -185,6 +199,8 @@ def main():
     ap.add_argument("--dist-n", type=int, default=32768, help="world size > 1: also run config C4 (one factorisation over all ranks, "
                     "RCCL) after the timed region and report it under \"dist_c4\"; 0 disables")
     ap.add_argument("--dist-steps", type=int, default=3)
+    ap.add_argument("--dist-rehearsal", action="store_true", help="one-GPU rehearsal of the C4 leg: a one-rank process group and a "
+                    "one-rank RCCL communicator (every collective runs as a self-copy)")
     ap.add_argument("--dist-timeout", type=float, default=240.0, help="seconds before the C4 leg is given up (the main line is printed regardless)")
     args = ap.parse_args()
 
@@ -197,11 +213,12 @@ def main():
     import torch  # plumbing only: device-wide synchronize + torch.distributed barrier / MAX
 
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_rehearsal:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if os.environ.get("GPX_BENCH_ONE_DEVICE"):  # rehearsal of the multi-rank plumbing on a one-GPU box only
         local_rank = 0
@@ -404,15 +421,15 @@ def main():
         def watchdog():
             if not done.wait(args.dist_timeout):
                 if rank == 0:
-                    out["dist_c4"] = {"error": f"no result within {args.dist_timeout:.0f} s"}
+                    out.setdefault("dist_c4", {})["error"] = f"not finished within {args.dist_timeout:.0f} s"
                     print(json.dumps(out), flush=True)
                 os._exit(0)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            out["dist_c4"] = dist_leg(args, rank, local_rank, world, dist, torch)
+            dist_leg(args, rank, local_rank, world, dist, torch, out)
         except Exception as exc:  # noqa: BLE001 -- reported, never fatal for the headline line
-            out["dist_c4"] = {"error": f"{type(exc).__name__}: {exc}"}
+            out.setdefault("dist_c4", {})["error"] = f"{type(exc).__name__}: {exc}"
         try:   # a rank that failed alone would leave the others in a collective: meet here or let the watchdog end it
             dist.barrier()
         finally:

@@ -97,6 +97,8 @@ SIGNATURES = {
     "gpx_dist_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "gpx_dist_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+    "gpx_dist_step_diag_early": (C.c_int, [C.c_void_p, C.c_int64]),
+    "gpx_dist_step_update_next_col": (C.c_int, [C.c_void_p, C.c_int64]),
     "gpx_dist_extract_z": (C.c_int, [C.c_void_p]),
     "gpx_dist_local_results": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.POINTER(C.c_int64), _dp, _dp, C.POINTER(C.c_int)]),
     "gpx_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),

@@ -264,12 +264,14 @@ extern "C" int gpx_dist_step_gather(gpx_handle* h, int64_t k) {
 
 // own trailing rows, matrix block columns [cfirst, cfirst + ncol) -= panel k (ncol < 0: all the way to the right);
 // on_trail != 0 enqueues on the bulk stream (the look-ahead driver), else on the main stream
-extern "C" int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t ncol, int on_trail) {
+// rows: this rank's block rows AFTER global block `after` (>= k): `after` = k is the plain update; the early-diagonal
+// schedule passes k+1 for block column k+1, whose diagonal block row the owner has already updated and factorised
+static int dist_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t ncol, int on_trail, int64_t after) {
   DistState& D = h->dist;
   const int nb = h->nb;
   if (cfirst < k + 1) cfirst = k + 1;
   if (ncol < 0 || cfirst + ncol > D.nblk) ncol = D.nblk - cfirst;
-  const int64_t s0 = first_slot_after(D, D.rank, k), c0 = k * nb;
+  const int64_t s0 = first_slot_after(D, D.rank, after), c0 = k * nb;
   const int64_t mrows = (D.nloc - s0) * nb;
   if (mrows <= 0 || ncol <= 0) return GPX_OK;
   GemmLaunch t;
@@ -280,6 +282,35 @@ extern "C" int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirs
   t.lower = 1; t.row_off = s0 * nb; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 0;
   t.cyc_P = D.P; t.cyc_r = D.rank; t.cyc_nb = nb;
   return launch_gemm_nt(h, on_trail ? h->s_trail : h->s_main, t);
+}
+
+extern "C" int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t ncol, int on_trail) {
+  return dist_update_cols(h, k, cfirst, ncol, on_trail, k);
+}
+
+// Early-diagonal schedule: block column k+1 without the block row k+1 on its owner (that block is gpx_dist_step_diag_early's)
+extern "C" int gpx_dist_step_update_next_col(gpx_handle* h, int64_t k) {
+  return dist_update_cols(h, k, k + 1, 1, 0, k + 1);
+}
+
+// Early-diagonal schedule, owner of block k1 = k+1 only, on the second chain stream: A_{k1,k1} -= L_{k1,k} L_{k1,k}^T with
+// the owner's OWN panel rows (no other rank's data: it need not wait for the all-gather of panel k), then potrf_diag
+// -> L_{k1,k1}, W_{k1}.  The caller orders it behind the panel solve of step k and the bulk update that last wrote
+// the block, and orders the broadcast of W_{k1} behind it.
+extern "C" int gpx_dist_step_diag_early(gpx_handle* h, int64_t k1) {
+  DistState& D = h->dist;
+  if (k1 < 1 || k1 >= D.nblk || owner_of(D, k1) != D.rank) return GPX_OK;
+  const int nb = h->nb;
+  const int64_t sl = slot_of(D, k1), c0 = (k1 - 1) * nb, c1 = k1 * nb;
+  GemmLaunch u;
+  u.A = D.L + sl * nb * D.ld + c0; u.lda = D.ld;
+  u.B = D.L + sl * nb * D.ld + c0; u.ldb = D.ld;
+  u.C = D.A + sl * nb * D.ld + c1; u.ldc = D.ld;
+  u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
+  u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
+  GPX_RET(launch_gemm_nt(h, h->s_main2, u));
+  return launch_potrf_diag(h, h->s_main2, nb, D.A + sl * nb * D.ld + c1, D.ld, D.L + sl * nb * D.ld + c1, D.ld, D.W,
+                           h->d_info, (int)c1);
 }
 
 extern "C" int gpx_dist_step_update(gpx_handle* h, int64_t k) {
@@ -424,10 +455,31 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, hipEventDisableTiming | hipEventDisableSystemFence));
     D.ev_s.push_back(a); D.ev_t.push_back(b);
   }
+  // Early diagonal (GPX_DIST_EARLY_DIAG=1, with the look-ahead): the owner of block k+1 updates and factorises its
+  // diagonal block on a second stream as soon as its own panel rows of step k are solved -- it needs nobody else's --
+  // so potrf_diag(k+1) (~30 us) runs beside the all-gather of panel k instead of behind it, and the broadcast of
+  // W_{k+1} only waits for the later of the two.  The collectives stay on ONE stream in ONE order on every rank.
+  const char* ed_env = getenv("GPX_DIST_EARLY_DIAG");
+  const bool early = dist_la && ed_env && atoi(ed_env) != 0;
+  hipStream_t e = h->s_main2;
+  while (early && (int64_t)D.ev_pan.size() < D.nblk) {
+    hipEvent_t a, b;
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming | hipEventDisableSystemFence));
+    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, hipEventDisableTiming | hipEventDisableSystemFence));
+    D.ev_pan.push_back(a); D.ev_diag.push_back(b);
+  }
   for (int64_t k = 0; k < D.nblk; ++k) {
-    GPX_RET(gpx_dist_step_diag(h, k));
+    if (!early || k == 0) GPX_RET(gpx_dist_step_diag(h, k));
+    else if (owner_of(D, k) == D.rank) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_diag[(size_t)k], 0));   // potrf_diag(k) ran early on `e`
     if (comm) GPX_NCCL_CHECK(h, ncclBroadcast(D.W, D.W, (size_t)nb * nb, ncclDouble, (int)owner_of(D, k), comm, s));
     GPX_RET(gpx_dist_step_panel(h, k));
+    if (early && k + 1 < D.nblk && owner_of(D, k + 1) == D.rank) {
+      GPX_HIP_CHECK(h, hipEventRecord(D.ev_pan[(size_t)k], s));
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(e, D.ev_pan[(size_t)k], 0));
+      if (k >= 1) GPX_HIP_CHECK(h, hipStreamWaitEvent(e, D.ev_t[(size_t)(k - 1)], 0));   // block (k+1,k+1) was last written by the bulk update of step k-1
+      GPX_RET(gpx_dist_step_diag_early(h, k + 1));
+      GPX_HIP_CHECK(h, hipEventRecord(D.ev_diag[(size_t)(k + 1)], e));
+    }
     // The all-gather moves only what is left below block k: the count is the largest number of panel rows any rank
     // still holds (every rank computes the same value), not the full-height chunk of step 0 -- half the bytes overall.
     int64_t step_rows = 0;
@@ -441,7 +493,8 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
     GPX_RET(gpx_dist_step_gather(h, k));
     D.gather_stride_rows = 0;
     if (k >= 1) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)(k - 1)], 0));   // column k+1 was last written by the bulk update of step k-1
-    GPX_RET(gpx_dist_step_update_cols(h, k, k + 1, 1, 0));
+    if (early) GPX_RET(gpx_dist_step_update_next_col(h, k));   // the owner's block (k+1,k+1) is already on its way through potrf_diag
+    else GPX_RET(gpx_dist_step_update_cols(h, k, k + 1, 1, 0));
     GPX_HIP_CHECK(h, hipEventRecord(D.ev_s[(size_t)k], s));
     GPX_HIP_CHECK(h, hipStreamWaitEvent(t, D.ev_s[(size_t)k], 0));
     GPX_RET(gpx_dist_step_update_cols(h, k, k + 2, -1, 1));
@@ -484,7 +537,9 @@ void gpx_dist_free(gpx_handle* h) {
   DistState& D = h->dist;
   for (auto e : D.ev_s) (void)hipEventDestroy(e);
   for (auto e : D.ev_t) (void)hipEventDestroy(e);
-  D.ev_s.clear(); D.ev_t.clear();
+  for (auto e : D.ev_pan) (void)hipEventDestroy(e);
+  for (auto e : D.ev_diag) (void)hipEventDestroy(e);
+  D.ev_s.clear(); D.ev_t.clear(); D.ev_pan.clear(); D.ev_diag.clear();
   void* bufs[] = {D.A, D.L, D.W, D.send, D.recv, D.panel, D.panel2, D.xloc, D.gid, D.type, D.r, D.z, D.small, D.red};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (D.comm) (void)ncclCommDestroy((ncclComm_t)D.comm);

@@ -154,6 +154,7 @@ struct DistState {
   double* panel2 = nullptr; int64_t panel2_cap = 0;   // panels alternate between two buffers: the bulk update of step k still
                                                         // reads panel k while step k+1 gathers the next one (look-ahead)
   std::vector<hipEvent_t> ev_s, ev_t;                   // look-ahead hand-overs of the RCCL driver
+  std::vector<hipEvent_t> ev_pan, ev_diag;              // early-diagonal schedule: panel rows solved (main -> second chain stream), potrf_diag done (back)
   double *xloc = nullptr, *r = nullptr, *z = nullptr, *small = nullptr, *red = nullptr;
   int64_t* gid = nullptr; int* type = nullptr;
   int64_t a_cap = 0, l_cap = 0, w_cap = 0, send_cap = 0, recv_cap = 0, panel_cap = 0, xloc_cap = 0, r_cap = 0, z_cap = 0,

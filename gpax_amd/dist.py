@@ -61,7 +61,10 @@ class _Rank:
 class LoopbackGroup:
     """P virtual ranks on ONE GPU; collectives are device-to-device copies.  Test transport only."""
 
-    def __init__(self, nranks, x, x_new, y_minus_m, device=0, nb=128):
+    def __init__(self, nranks, x, x_new, y_minus_m, device=0, nb=128, early_diag=False):
+        """``early_diag``: play the early-diagonal schedule of ``gpx_dist_fit_predict`` (the owner of block k+1 updates
+        and factorises its diagonal block from its own panel rows, before the all-gather of panel k)."""
+        self.early_diag = early_diag
         self.P = nranks
         self.ranks = []
         for r in range(nranks):
@@ -82,7 +85,8 @@ class LoopbackGroup:
         bufs = [r.buffers() for r in R]
         for k in range(R[0].nsteps):
             owner = k % self.P
-            R[owner].core._check(R[owner].lib.gpx_dist_step_diag(R[owner].h, k), "step_diag")
+            if not (self.early_diag and k >= 1):   # early schedule: block k was factorised during step k-1
+                R[owner].core._check(R[owner].lib.gpx_dist_step_diag(R[owner].h, k), "step_diag")
             R[owner].core.synchronize()
             for q in range(self.P):  # "ncclBroadcast" of W_k from the owner
                 if q != owner:
@@ -90,13 +94,20 @@ class LoopbackGroup:
             for r in R:
                 r.core._check(r.lib.gpx_dist_step_panel(r.h, k), "step_panel")
                 r.core.synchronize()
+            if self.early_diag and k + 1 < R[0].nsteps:   # before the "all-gather": only the owner's own panel rows are needed
+                nxt = R[(k + 1) % self.P]
+                nxt.core._check(nxt.lib.gpx_dist_step_diag_early(nxt.h, k + 1), "step_diag_early")
+                nxt.core.synchronize()
             for q in range(self.P):  # "ncclAllGather": every rank's send chunk into slot r of every recv buffer
                 for r in range(self.P):
                     dst = bufs[q]["recv"] + r * bufs[q]["chunk"] * 8
                     R[q].core._check(R[q].lib.gpx_dist_copy(R[q].h, dst, bufs[r]["send"], bufs[q]["chunk"]), "allgather")
             for r in R:  # the look-ahead driver's split of the update: block column k+1 first, then the rest
                 r.core._check(r.lib.gpx_dist_step_gather(r.h, k), "step_gather")
-                r.core._check(r.lib.gpx_dist_step_update_cols(r.h, k, k + 1, 1, 0), "step_update_cols (next)")
+                if self.early_diag:
+                    r.core._check(r.lib.gpx_dist_step_update_next_col(r.h, k), "step_update_next_col")
+                else:
+                    r.core._check(r.lib.gpx_dist_step_update_cols(r.h, k, k + 1, 1, 0), "step_update_cols (next)")
                 r.core._check(r.lib.gpx_dist_step_update_cols(r.h, k, k + 2, -1, 0), "step_update_cols (rest)")
                 r.core.synchronize()
         owner = R[0].r_owner

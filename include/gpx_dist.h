@@ -45,6 +45,11 @@ int gpx_dist_step_update(gpx_handle* h, int64_t k);   /* after the all-gather: o
  * on the main (on_trail = 0) or the bulk stream */
 int gpx_dist_step_gather(gpx_handle* h, int64_t k);
 int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t ncol, int on_trail);
+/* early-diagonal schedule (GPX_DIST_EARLY_DIAG=1 in gpx_dist_fit_predict): on the owner of block k1, A_{k1,k1} -=
+ * L_{k1,k1-1} L_{k1,k1-1}^T from its own panel rows and potrf_diag(k1), on the handle's second chain stream; and the
+ * update of block column k+1 that leaves that block row out on its owner */
+int gpx_dist_step_diag_early(gpx_handle* h, int64_t k1);
+int gpx_dist_step_update_next_col(gpx_handle* h, int64_t k);
 int gpx_dist_buffers(gpx_handle* h, void** w, int64_t* w_count, void** send, void** recv, int64_t* chunk_count,
                      void** z, int64_t* z_count);
 int gpx_dist_copy(gpx_handle* h, void* dst, const void* src, int64_t count);   /* device-to-device, doubles */

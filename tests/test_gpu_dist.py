@@ -71,7 +71,32 @@ def test_rccl_driver_world_size_1():
     assert np.abs(mean - mean_ref).max() <= 1e-8 and np.abs(var - var_ref).max() <= 1e-8
 
 
-@pytest.mark.parametrize("lookahead", ["1", "0"])
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_loopback_early_diagonal_schedule(nranks):
+    """The early-diagonal schedule (owner of block k+1 factorises it from its own panel rows before the all-gather of
+    panel k; block column k+1 is then updated without that block row): same results as the oracle, not-PD index included."""
+    import gpax_amd
+    from gpax_amd.dist import LoopbackGroup
+    from oracle import gp_oracle as orc
+
+    n, m, d = 900, 140, 5
+    x, y, xn, p = orc.synthetic_problem(n, d, m, seed=31 + nranks)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    grp = LoopbackGroup(nranks, x, xn, y - 1.0, early_diag=True)
+    try:
+        info, logp, mean, var = grp.fit_predict(prm, np.ones(m), 0.0)
+        logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, p)
+        assert info == 0 and abs(logp - logp_ref) <= 1e-10 * abs(logp_ref)
+        assert np.abs(mean - mean_ref).max() <= 1e-8 and np.abs(var - var_ref).max() <= 1e-8
+        noise = np.full(n, 0.01)
+        noise[400] = -5.0
+        info, logp, _, _ = grp.fit_predict(gpax_amd.make_params(0, 1.0, 1.0, None, noise, 1e-6), np.ones(m), 0.0)
+        assert info == 401 and not np.isfinite(logp)
+    finally:
+        grp.close()
+
+
+@pytest.mark.parametrize("lookahead", ["1", "0", "early"])
 def test_rccl_driver_single_rank_communicator(lookahead, monkeypatch):
     """The RCCL calls themselves (ncclCommInitRank, ncclBroadcast of W_k and z, the shrinking ncclAllGather of the
     panel, the two ncclAllReduce of the epilogue) on the driver's streams, through a one-rank communicator: the only
@@ -80,7 +105,8 @@ def test_rccl_driver_single_rank_communicator(lookahead, monkeypatch):
     from gpax_amd.dist import DistributedStep
     from oracle import gp_oracle as orc
 
-    monkeypatch.setenv("GPX_DIST_LOOKAHEAD", lookahead)
+    monkeypatch.setenv("GPX_DIST_LOOKAHEAD", "1" if lookahead == "early" else lookahead)
+    monkeypatch.setenv("GPX_DIST_EARLY_DIAG", "1" if lookahead == "early" else "0")
     x, y, xn, p = orc.synthetic_problem(1100, 8, 150, seed=11)
     prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
     step = DistributedStep(x, xn, y - 1.0, device=0, force_comm=True)

@@ -12,14 +12,15 @@ d, m = 8, 1000
 rng = np.random.default_rng(0)
 x = rng.uniform(-1, 1, (n, d)); xn = rng.uniform(-1, 1, (m, d)); y = rng.standard_normal(n)
 p = gpax_amd.make_params(0, 1.0, 1.0, None, np.array([0.0067]), 1e-6)
-for force in (False, True):
+for force, early in ((False, "0"), (True, "0"), (True, "1")):
+    os.environ["GPX_DIST_EARLY_DIAG"] = early
     st = DistributedStep(x, xn, y, device=0, force_comm=force)
     st.fit_predict(p, np.ones(m), 0.0)
     t0 = time.perf_counter()
     for _ in range(steps):
         info, logp, mean, var = st.fit_predict(p, np.ones(m), 0.0)
     dt = (time.perf_counter() - t0) / steps
-    print(f"N={n} one rank, communicator={force}: {dt * 1e3:.2f} ms/step  info={info} logp={logp:.6f}", flush=True)
+    print(f"N={n} one rank, communicator={force}, early diagonal={early}: {dt * 1e3:.2f} ms/step  info={info} logp={logp:.6f}", flush=True)
     st.close()
 c = gpax_amd.Core(0)
 c.set_train(x); c.set_test(xn); c.set_targets(y, np.ones(m))
