@@ -492,15 +492,21 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   GEMM_TL(3, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));
   const double* Ag = g.A + m0 * g.lda;
   const double* Bg = g.B + n0 * g.ldb;
+  // B lower triangular (the panel solve against W_k): B[n][k] = 0 for k > n, so the tile columns left of K/2 need
+  // the first half of K only -- a quarter of the panel solve's loads and MFMAs
+  const int nhalf = (g.b_lower_tri && n0 + 32 <= KH) ? 1 : 2;
   v2d ra[2][NCH], rb[2][NCH];
 #pragma unroll
-  for (int hf = 0; hf < 2; ++hf)
+  for (int hf = 0; hf < 2; ++hf) {
+    if (hf < nhalf) {
 #pragma unroll
-    for (int it = 0; it < NCH; ++it) {
-      const int c = tid + it * 256;
-      ra[hf][it] = *reinterpret_cast<const v2d*>(Ag + (int64_t)(c / (KH / 2)) * g.lda + hf * KH + 2 * (c % (KH / 2)));
-      rb[hf][it] = *reinterpret_cast<const v2d*>(Bg + (int64_t)(c / (KH / 2)) * g.ldb + hf * KH + 2 * (c % (KH / 2)));
+      for (int it = 0; it < NCH; ++it) {
+        const int c = tid + it * 256;
+        ra[hf][it] = *reinterpret_cast<const v2d*>(Ag + (int64_t)(c / (KH / 2)) * g.lda + hf * KH + 2 * (c % (KH / 2)));
+        rb[hf][it] = *reinterpret_cast<const v2d*>(Bg + (int64_t)(c / (KH / 2)) * g.ldb + hf * KH + 2 * (c % (KH / 2)));
+      }
     }
+  }
   const int fr = lane & 15, fk = lane >> 4;
   double* cp = g.C + (m0 + wm * 16 + fk) * g.ldc + n0 + wn * 16 + fr;   // row = fk + 4r, col = fr
   v4d cin = {0.0, 0.0, 0.0, 0.0};
@@ -513,6 +519,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int hf = 0; hf < 2; ++hf) {
+    if (hf >= nhalf) break;
     if (hf) __syncthreads();   // everyone is done reading the first half
 #pragma unroll
     for (int it = 0; it < NCH; ++it) {
