@@ -309,6 +309,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_LA_ROWS"))) h->la_rows = std::max(atoi(env), 0);
   if ((env = getenv("GPX_COL_SPLIT"))) h->col_split = std::max(atoi(env), 0);
   if ((env = getenv("GPX_NEAR_BLOCK"))) h->near_block = atoi(env) != 0;
+  if ((env = getenv("GPX_FUSE_BAND"))) h->fuse_band = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -383,6 +384,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "la_rows")) { h->la_rows = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "col_split")) { h->col_split = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "near_block")) { h->near_block = value != 0; return GPX_OK; }
+  if (!strcmp(name, "fuse_band")) { h->fuse_band = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -400,6 +402,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "la_rows")) { *value = h->la_rows; return GPX_OK; }
   if (!strcmp(name, "col_split")) { *value = h->col_split; return GPX_OK; }
   if (!strcmp(name, "near_block")) { *value = h->near_block; return GPX_OK; }
+  if (!strcmp(name, "fuse_band")) { *value = h->fuse_band; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -580,7 +583,7 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
   if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, fl));
   if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
   if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
-  GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, 2 * (int64_t)std::max<size_t>(nblk, 64)));
+  GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, 3 * (int64_t)std::max<size_t>(nblk, 64)));   // flagsU, flagsW, flagsS
   GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, 2 * (int64_t)h->nb * h->nb));
   while (h->ev_far.size() < nblk) {
     hipEvent_t a, b;
@@ -746,7 +749,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   const bool resident = h->resident != 0 && !h->in_capture && h->prof_mode != 1 && nblk >= 3;
   hipStream_t P2 = resident ? h->s_main2 : P;
   const unsigned n_signal = (unsigned)((nb / 32) * (nb / 32 + 1) / 2);   // lower 32x32 tiles of a diagonal block
-  if (resident && !h->flags_clean) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(2 * nblk) * sizeof(unsigned), P));
+  if (resident && !h->flags_clean) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(3 * nblk) * sizeof(unsigned), P));
   h->flags_clean = false;
   // resident == 2: every hand-over of the chain is in-kernel.  The diagonal blocks run on one stream, the two band
   // kernels on the other; S = A W_k^T is launched while potrf_diag(k) still runs and sleeps on the flag that kernel
@@ -756,6 +759,8 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   const bool chain2 = resident && h->resident >= 2;
   unsigned* flagsU = h->d_flags;            // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
   unsigned* flagsW = h->d_flags + nblk;     // [k]: W_k published (S = A W_k^T of step k waits)
+  unsigned* flagsS = h->d_flags + 2 * nblk; // [k]: tiles of S published (fused band kernel: its second phase waits)
+  const bool fuse_band = chain2 && h->fuse_band != 0;
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
@@ -829,15 +834,23 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     g.M = nb; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
     g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
     if (chain2) { g.wait_flag = flagsW + k; g.wait_count = 1; g.wait_info = h->d_info; }   // W_k arrives in-kernel from potrf_diag(k)
-    prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
-    GPX_RET(launch_gemm_nt(h, PB, g));
-    prof_end(h, PB);
     GemmLaunch u;
     u.A = S; u.lda = nb; u.B = S; u.ldb = nb;
     u.C = A + r0 * ld + r0; u.ldc = ld;
     u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
     u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
     if (resident) u.signal = flagsU + k;   // potrf_diag(k+1) is already resident and polls this counter
+    if (fuse_band) {   // both band kernels in one launch: S's tiles are handed over through flagsS[k]
+      g.signal = flagsS + k;
+      u.wait_flag = flagsS + k; u.wait_count = (unsigned)((nb / 32) * (nb / 32)); u.wait_info = h->d_info;
+      prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, 2.0 * (double)nb * nb * nb, 8.0 * 6.0 * nb * nb);
+      GPX_RET(launch_chain_band(h, PB, g, u));
+      prof_end(h, PB);
+      return GPX_OK;
+    }
+    prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
+    GPX_RET(launch_gemm_nt(h, PB, g));
+    prof_end(h, PB);
     prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
     GPX_RET(launch_gemm_nt(h, PB, u));
     prof_end(h, PB);
@@ -1128,7 +1141,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   double fl, by;
   g.zero_info = h->d_info;
   if (h->d_flags) {   // the hand-over flags of the split-panel schedule are cleared by the same launch
-    g.zero_flags = h->d_flags; g.n_zero_flags = (int)(2 * (npad / h->nb));
+    g.zero_flags = h->d_flags; g.n_zero_flags = (int)(3 * (npad / h->nb));
     h->flags_clean = true;
   }
   gram_cost(0, n, &fl, &by);

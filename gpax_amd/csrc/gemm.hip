@@ -464,19 +464,16 @@ __global__ __launch_bounds__(256, GEMM_PERSIST_WAVES) void gemm_nt_persist_kerne
 // (A register-only variant with per-lane contiguous K chunks was tried and measured slower:
 // its loads touch 64 different cache lines per instruction.)
 template <int K>
-__global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
+__device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0, const int64_t n0, double* __restrict__ As,
+                                             double* __restrict__ Bs) {
   // LDS holds HALF of K at a time (K/2 + 4 doubles per row): 34 KB at K = 128, so four workgroups fit a CU and even the widest
   // panel of the factorisation is resident in a single round.  All global loads of BOTH halves are in
   // flight together; the second half waits in registers while the first is in the MFMAs.
   constexpr int KH = K / 2;
   constexpr int LD = KH + 4;   // stride 8 (mod 64) dwords: conflict-free ds_read_b128 fragment reads
   constexpr int NCH = 32 * (KH / 2) / 256;   // 16-B chunks per thread, operand and half
-  __shared__ __attribute__((aligned(16))) double As[32 * LD];
-  __shared__ __attribute__((aligned(16))) double Bs[32 * LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
-  if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
   if (g.wait_flag) {   // resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
     if (tid == 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -558,6 +555,63 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
     cp[(int64_t)(4 * r) * g.ldc] = v;
   }
   GEMM_TL_END();
+}
+
+template <int K>
+__global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) double As[32 * (K / 2 + 4)];
+  __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
+  const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+  if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
+  onepass_body<K>(g, m0, n0, As, Bs);
+}
+
+// The two band kernels of the chain in ONE launch (split-panel schedule with in-kernel hand-overs): every workgroup
+// first forms its 32x32 tile of S = A_{k+1,k} W_k^T (gs: sleeps on potrf_diag(k)'s flag, publishes the tile and counts
+// into gs.signal), then the workgroups of the lower tiles wait for all (nb/32)^2 tiles of S (gu.wait_flag = gs.signal)
+// and apply A_{k+1,k+1} -= S S^T to their tile (gu: publishes to the counter potrf_diag(k+1) polls).  The second kernel's
+// launch -- ~2 us between the two even back to back on one stream -- becomes a flag round trip inside a launch whose
+// 16 workgroups are all resident (they never wait for a workgroup that is not: phase 1 waits only for potrf_diag).
+template <int K>
+__global__ __launch_bounds__(256, 2) void chain_band_kernel(GemmArgs gs, GemmArgs gu) {
+  __shared__ __attribute__((aligned(16))) double As[32 * (K / 2 + 4)];
+  __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
+  const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+  onepass_body<K>(gs, m0, n0, As, Bs);
+  if (n0 > m0) return;   // strictly upper tile of the diagonal block
+  onepass_body<K>(gu, m0, n0, As, Bs);
+}
+
+static void fill_args(GemmArgs& g, const GemmLaunch& L) {
+  g.A = L.A; g.B = L.B; g.C = L.C; g.lda = L.lda; g.ldb = L.ldb; g.ldc = L.ldc;
+  g.M = L.M; g.N = L.N; g.K = L.K; g.alpha = L.alpha; g.beta = L.beta;
+  g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
+  g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
+  g.a_upper_tri = L.a_upper_tri;
+  g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
+  g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
+  g.tl_id = -1;
+}
+
+// S (nb x nb, L.N == L.M == L.K == nb) and the update of the diagonal block in one launch; both launches as the caller
+// would have issued them separately, S.signal / U.wait_flag pointing at the same zeroed counter
+int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch& S, const GemmLaunch& U) {
+  const int64_t nb = S.K;
+  if ((nb != 128 && nb != 64) || S.M != nb || S.N != nb || U.M != nb || U.N != nb || U.K != nb || !S.signal || U.wait_flag != S.signal ||
+      U.wait_count != (unsigned)((nb / 32) * (nb / 32))) {
+    gpx_set_error(h, "chain_band: contract violated");
+    return GPX_ERR_ARG;
+  }
+  GemmArgs gs, gu;
+  fill_args(gs, S); fill_args(gu, U);
+#ifdef GPX_TIMELINE
+  gs.tl_id = g_tl_launch++; gu.tl_id = g_tl_launch++;
+#endif
+  dim3 grid((unsigned)(nb / 32), (unsigned)(nb / 32));
+  if (nb == 128) hipExtLaunchKernelGGL((chain_band_kernel<128>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gs, gu);
+  else hipExtLaunchKernelGGL((chain_band_kernel<64>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gs, gu);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
 }
 
 // GPX_TILE_MAP: 0 (default) 1-D row-major enumeration of the lower trapezoid, 1 XCD-aware super-tiles, 2 plain 2-D grid
