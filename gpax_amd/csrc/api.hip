@@ -310,6 +310,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_COL_SPLIT"))) h->col_split = std::max(atoi(env), 0);
   if ((env = getenv("GPX_NEAR_BLOCK"))) h->near_block = atoi(env) != 0;
   if ((env = getenv("GPX_FUSE_BAND"))) h->fuse_band = atoi(env) != 0;
+  if ((env = getenv("GPX_BORDER_SIDE"))) h->border_side = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -344,6 +345,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   if (h->s_main) (void)hipStreamDestroy(h->s_main);
   if (h->s_main2) (void)hipStreamDestroy(h->s_main2);
   if (h->ev_chain2) (void)hipEventDestroy(h->ev_chain2);
+  if (h->ev_build) (void)hipEventDestroy(h->ev_build);
   if (h->d_flags) (void)hipFree(h->d_flags);
   if (h->s_trail) (void)hipStreamDestroy(h->s_trail);
   if (h->s_far) (void)hipStreamDestroy(h->s_far);
@@ -385,6 +387,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "col_split")) { h->col_split = (int)std::max<int64_t>(value, 0); return GPX_OK; }
   if (!strcmp(name, "near_block")) { h->near_block = value != 0; return GPX_OK; }
   if (!strcmp(name, "fuse_band")) { h->fuse_band = value != 0; return GPX_OK; }
+  if (!strcmp(name, "border_side")) { h->border_side = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -403,6 +406,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "col_split")) { *value = h->col_split; return GPX_OK; }
   if (!strcmp(name, "near_block")) { *value = h->near_block; return GPX_OK; }
   if (!strcmp(name, "fuse_band")) { *value = h->fuse_band; return GPX_OK; }
+  if (!strcmp(name, "border_side")) { *value = h->border_side; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -583,6 +587,7 @@ static int ensure_events(gpx_handle* h, size_t nblk) {
   if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, fl));
   if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
   if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
+  if (!h->ev_build) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_build, fl));
   GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, 3 * (int64_t)std::max<size_t>(nblk, 64)));   // flagsU, flagsW, flagsS
   GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, 2 * (int64_t)h->nb * h->nb));
   while (h->ev_far.size() < nblk) {
@@ -1152,11 +1157,21 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
                                       (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
   }
   GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
-  GPX_RET(cross_gram(s));
-  // the r row and the unused (zero) border rows in one launch.  (Building most of K on the bulk stream while the
-  // chain already factorises was tried: no gain at N = 4096, 1.907 vs 1.905 ms -- the first steps are bound by
-  // that stream.)
-  GPX_RET(launch_border_rows(h, s, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
+  // The border (k_cross rows, the r row, the zero rows) is not read by the chain before the very last panel: with the
+  // split-panel schedule it is built on the panel stream, whose first kernel (the panel of block column 0) is its
+  // first reader, while the chain stream goes straight from K to potrf_diag(0) -- ~30 us off the head of the step.
+  // (Building most of K itself on the bulk stream while the chain already factorises was tried: no gain at N = 4096,
+  // 1.907 vs 1.905 ms -- the first steps are bound by that stream.)
+  const bool border_on_q = h->border_side && h->lookahead != 0 && h->depth >= 3 && npad / h->nb >= 2 && !h->in_capture && h->prof_mode != 1;
+  hipStream_t sb = s;
+  if (border_on_q) {
+    sb = h->s_far;
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_build, s));
+    GPX_HIP_CHECK(h, hipStreamWaitEvent(sb, h->ev_build, 0));
+  }
+  GPX_RET(cross_gram(sb));
+  // the r row and the unused (zero) border rows in one launch
+  GPX_RET(launch_border_rows(h, sb, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
 
   const int lrc = factor_loop(h, rows);
   h->flags_clean = false;   // consumed by the split-panel loop, or unused by the others: never carried into another call

@@ -197,6 +197,7 @@ struct gpx_handle {
   unsigned* d_flags = nullptr; int64_t flags_cap = 0;
   bool flags_clean = false;   // the flags were cleared by the gram launch of this call (no memset needed)   // per-step tile counters of the resident start
   hipEvent_t ev_chain2 = nullptr;
+  hipEvent_t ev_build = nullptr;   // K built on the chain stream -> the border rows are built on the panel stream
   int resident = 2;                // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
                                    // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag)
   std::string err;
@@ -209,6 +210,7 @@ struct gpx_handle {
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 32;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 48;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int border_side = 1; // split-panel schedule: k_cross / r / zero border rows are built on the panel stream, off the chain
   int fuse_band = 1;   // in-kernel hand-over schedule: S = A W_k^T and A -= S S^T in one launch
   int near_block = 1;  // grouped phases: the next group's columns are updated by Q in a launch of its own, the bulk launch starts behind them
   int col_split = 0;   // the two look-ahead columns are updated by separate kernels while at least this many block columns are left to the bulk update; 0 = never

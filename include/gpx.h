@@ -182,6 +182,8 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  hardware-counter collection, inside a stream capture and under per-launch bracketing)
  *   "pair_min" / "quad_min"  group the bulk updates two / four panels at a time while more than this many block
  *                  columns remain; 0 = never (32 / 48)
+ *   "border_side"  split-panel schedule: the border (k_cross rows, r row) is built on the panel stream, whose first kernel is its
+ *                  first reader, instead of on the chain stream in front of potrf_diag(0) (1)
  *   "fuse_band"    in-kernel hand-over schedule: the chain's two band kernels (S = A W_k^T, A -= S S^T) run as ONE launch
  *                  whose second phase waits on a device counter for the first phase's tiles (1)
  *   "near_block"   grouped phases: at a group end the next group's block columns are updated by the panel stream in a
