@@ -804,6 +804,17 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     // packet behind it), else recorded right after it -- NOT after the two band kernels (measured 1.91 -> 2.12 ms
     // per N = 4096 step when the panel stream learns of W_k 12 us later)
     const bool need_w = rows - r0 > 0;
+    if (need_w && k + 1 >= nblk && !kinv && k >= 1) {
+      // The last panel (below) reads the border rows of column k on THIS stream; their last writer is Q's column update
+      // of step k-1.  Nothing else orders the two (potrf_diag(k) only waits for the band kernel of step k-1, which
+      // waited for Q's step k-2): wait for it here, in front of potrf_diag, where it costs nothing -- that update is
+      // normally long finished.  (Without it the race was real at two block columns once the border was built on
+      // the panel stream: one wrong posterior in ~200 runs of the test suite.)
+#ifndef GPX_NO_LASTPANEL_WAIT   // (diagnostic switch: tools/soak.py reproduces the race without the wait)
+      if (!await(far_rec[(size_t)(k - 1)])) return GPX_ERR_HIP;
+      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
+#endif
+    }
     prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
     GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
                               h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr,

@@ -475,6 +475,7 @@ __device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   if (g.wait_flag) {   // resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
+    GEMM_TL(6, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));   // (timeline build) became resident
     if (tid == 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (__hip_atomic_load(g.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {

@@ -214,7 +214,7 @@ struct gpx_handle {
   int fuse_band = 1;   // in-kernel hand-over schedule: S = A W_k^T and A -= S S^T in one launch
   int near_block = 1;  // grouped phases: the next group's columns are updated by Q in a launch of its own, the bulk launch starts behind them
   int col_split = 0;   // the two look-ahead columns are updated by separate kernels while at least this many block columns are left to the bulk update; 0 = never
-  int la_rows = 4096;  // look-ahead column updates use 64x64 tiles while at least this many rows remain below (-1 % at N = 8192/16384); 0 = never
+  int la_rows = 6144;  // look-ahead column updates use 64x64 tiles while at least this many rows remain below (-1 % at N = 8192/16384; N = 4096 never gets there); 0 = never
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
   // resident inputs

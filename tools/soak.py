@@ -3,12 +3,17 @@ bitwise with the first one of its size (the schedule is deterministic) and info 
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpax_amd import _lib
+if len(sys.argv) > 1 and sys.argv[1] != "default":   # python tools/soak.py [lib.so]: a diagnostic build of the library
+    _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 import gpax_amd
 rng = np.random.default_rng(0)
 c = gpax_amd.Core(0)
 t0 = time.time()
 total = 0
-for n, m, reps in ((300, 17, 400), (700, 50, 400), (1500, 100, 300), (2500, 333, 200), (4096, 1000, 300), (6000, 10, 50)):
+# (200, 250) and (256, 1000): two block columns with a tall border -- the shape at which the last border panel once raced
+# with the panel stream's last column update
+for n, m, reps in ((200, 250, 3000), (256, 1000, 2000), (300, 17, 400), (700, 50, 400), (1500, 100, 300), (2500, 333, 200), (4096, 1000, 300), (6000, 10, 50)):
     d = 5
     x = rng.uniform(-1, 1, (n, d)); xn = rng.uniform(-1, 1, (m, d)); y = rng.standard_normal(n)
     c.set_train(x); c.set_test(xn); c.set_targets(y, np.ones(m))

@@ -53,6 +53,9 @@ for (kind0, tstart, a, b), t in zip(rec, us):
         N_, beta = b // 1000000, b % 1000000
         what = "mini-panel" if (a == nb and N_ == nb and not beta) else ("mini-update" if (a == nb and N_ == nb) else ("Q panel" if not beta else "Q col-update"))
         rows.append((t, what, f"M={a} N={N_}{dur}"))
+    elif kind == 6:
+        N_, beta = b // 1000000, b % 1000000
+        rows.append((t, "  resident:", ("mini-update" if beta else "mini-panel") + f" M={a} N={N_}"))
     elif kind == 4:
         rows.append((t, "T bulk", f"M={a} N={b // 1000000} K={b % 1000000}{dur}"))
 print(f"{cnt} records; step spans {us[-1]:.1f} us from first to last logged start")
