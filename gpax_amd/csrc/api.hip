@@ -311,6 +311,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_NEAR_BLOCK"))) h->near_block = atoi(env) != 0;
   if ((env = getenv("GPX_FUSE_BAND"))) h->fuse_band = atoi(env) != 0;
   if ((env = getenv("GPX_BORDER_SIDE"))) h->border_side = atoi(env) != 0;
+  if ((env = getenv("GPX_DIAG_BAND"))) h->diag_band = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -388,6 +389,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "near_block")) { h->near_block = value != 0; return GPX_OK; }
   if (!strcmp(name, "fuse_band")) { h->fuse_band = value != 0; return GPX_OK; }
   if (!strcmp(name, "border_side")) { h->border_side = value != 0; return GPX_OK; }
+  if (!strcmp(name, "diag_band")) { h->diag_band = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -407,6 +409,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "near_block")) { *value = h->near_block; return GPX_OK; }
   if (!strcmp(name, "fuse_band")) { *value = h->fuse_band; return GPX_OK; }
   if (!strcmp(name, "border_side")) { *value = h->border_side; return GPX_OK; }
+  if (!strcmp(name, "diag_band")) { *value = h->diag_band; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -792,6 +795,47 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   // stream capture and under per-launch profiling, where they are recorded behind the kernel as usual
   const bool attach = !h->in_capture && h->prof_mode != 1;
 
+  // ---- "diagonal block in the band kernel" (fused band kernel, ungrouped steps).  The column update of step j used to
+  // cover column j+2 from its diagonal block down, behind the wait for the bulk launch that last wrote that column, and
+  // the band kernel of step j+1 waited for all of it -- on alternate block columns of the chain-bound middle of the
+  // factorisation that update (slowed 2x by the bulk launch it shares the CUs with) finished 10-15 us after
+  // potrf_diag(j+1) (profiles/r01_step_timeline_mid.txt).  Now the panel stream's update of column j+2 starts BELOW
+  // the diagonal block, the hand-over event is recorded behind the update of column j+1 alone, and the band kernel
+  // of step j+1 applies panel j to block (j+2,j+2) itself, in a phase 0 that runs while it waits, resident, for
+  // potrf_diag(j+1) -- same tile kernel, same order of the two subtractions, bit-identical result.
+  // dib[k]: the band kernel of step k has that phase 0 (for panel k-1 on block (k+1,k+1)); band_t[k]: the bulk launch
+  // (its step) that last wrote that block and must have finished, or -1.  Both follow from k alone (the grouping is a
+  // function of k), so the chain and the side streams agree without talking.
+  const bool use_dib = fuse_band && h->diag_band != 0 && !kinv;
+  std::vector<char> dib((size_t)nblk + 2, 0);
+  std::vector<int64_t> band_t((size_t)nblk + 2, -1);
+  if (use_dib) {
+    const int64_t pm = h->pair_min, qm = h->quad_min;
+    auto gsz = [&](int64_t left) -> int64_t { return (qm > 0 && left > qm) ? 4 : ((pm > 0 && left > pm) ? 2 : 1); };
+    int64_t lt = -1, ge = -1, ti = -1, tf = nblk;
+    for (int64_t j = 0; j < nblk; ++j) {
+      if (j > ge) ge = j + gsz(nblk - j) - 1;
+      const int64_t rows = rows_at(j);
+      if (rows - (j + 1) * nb <= 0 || j + 1 >= nblk) continue;
+      int64_t near = 0;
+      if (j == ge && h->near_block) {
+        const int64_t gn = gsz(nblk - (j + 1));
+        if (gn >= 2) near = std::max<int64_t>(0, std::min<int64_t>(gn, nblk - (j + 3)));
+      }
+      const int64_t mr = rows - (j + 2) * nb, ncb = std::min<int64_t>(2, nblk - (j + 1));
+      if (mr > 0 && ncb > 1 && j - lt == 1) {
+        dib[(size_t)(j + 1)] = 1;
+        band_t[(size_t)(j + 1)] = (ti >= 0 && j + 2 >= tf) ? ti : -1;
+      }
+      if (j == ge) {
+        if (nblk - (j + 3 + near) > 0) { ti = j; tf = j + 3 + near; }
+        lt = j;
+      }
+    }
+  }
+  std::unique_ptr<std::atomic<int>[]> trail_rec(new std::atomic<int>[(size_t)nblk]);
+  for (int64_t k = 0; k < nblk; ++k) trail_rec[(size_t)k].store(0);
+
   // ---- the chain (stream P) at step k: potrf, then the diagonal band
   auto chain = [&](int64_t k) -> int {
     // resident == 1: consecutive steps alternate between the two chain streams; resident == 2: potrf_diag on
@@ -859,8 +903,21 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     if (fuse_band) {   // both band kernels in one launch: S's tiles are handed over through flagsS[k]
       g.signal = flagsS + k;
       u.wait_flag = flagsS + k; u.wait_count = (unsigned)((nb / 32) * (nb / 32)); u.wait_info = h->d_info;
-      prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, 2.0 * (double)nb * nb * nb, 8.0 * 6.0 * nb * nb);
-      GPX_RET(launch_chain_band(h, PB, g, u));
+      GemmLaunch z;   // phase 0: block (k+1,k+1) -= L_{k+1,k-1} L_{k+1,k-1}^T (panel k-1), see dib[] above
+      const bool phase0 = dib[(size_t)k] != 0;
+      if (phase0) {
+        if (band_t[(size_t)k] >= 0) {   // the bulk launch that last wrote the block
+          if (!await(trail_rec[(size_t)band_t[(size_t)k]])) return GPX_ERR_HIP;
+          GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_trail[(size_t)band_t[(size_t)k]], 0));
+        }
+        z.A = L + r0 * ld + (k - 1) * nb; z.lda = ld;
+        z.B = z.A; z.ldb = ld;
+        z.C = A + r0 * ld + r0; z.ldc = ld;
+        z.M = nb; z.N = nb; z.K = nb; z.alpha = -1.0; z.beta = 1.0;
+        z.lower = 1; z.row_off = 0; z.col_off = 0; z.b_lower_tri = 0; z.small_tile = 1;
+      }
+      prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (phase0 ? 3.0 : 2.0) * (double)nb * nb * nb, 8.0 * 6.0 * nb * nb);
+      GPX_RET(launch_chain_band(h, PB, phase0 ? &z : nullptr, g, u));
       prof_end(h, PB);
       return GPX_OK;
     }
@@ -962,8 +1019,10 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     // off everything P waits for, was tried with and without grouped updates: 1.94-2.02 vs 1.88 ms at N = 4096.)
     const int64_t rr = (k + 2) * nb, mr = rows - rr;
     bool far_attached = false;
-    auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last) -> int {
-      GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= rr, -= panels [kfirst, kfirst+npan)
+    auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last, int64_t skip_blocks = 0) -> int {
+      GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= rr (+ skip_blocks block rows), -= panels [kfirst, kfirst+npan)
+      const int64_t rr = (k + 2 + skip_blocks) * nb, mr = rows - rr;
+      if (mr <= 0) return GPX_OK;
       if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
       t.A = L + rr * ld + kfirst * nb; t.lda = ld;
       t.B = L + cfirst * nb * ld + kfirst * nb; t.ldb = ld;
@@ -996,7 +1055,16 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       // behind the wait, the update -- slowed 3-4x by the bulk kernel it shares the CUs with -- and the next panel
       // behind it took longer than one bulk update, and the bulk stream idled ~18 us per step at N = 4096.
       const bool split = ncb > 1 && (npan2 > 1 || (h->col_split > 0 && nblk - (k + 3) >= h->col_split));
-      if (split) {
+      if (dib[(size_t)(k + 1)]) {
+        // column k+1 alone carries the hand-over to the chain; column k+2 from BELOW its diagonal block, behind the
+        // wait for the bulk launch (the band kernel of step k+1 applies panel k to that block itself)
+        GPX_RET(col_update(k + 1, 1, k, 1, true));
+        if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
+        far_attached = true;   // recorded (or attached) already: not again behind the second column
+        far_rec[(size_t)k].store(1, std::memory_order_release);
+        GPX_RET(wait_for_t());
+        GPX_RET(col_update(k + 2, 1, k, 1, false, 1));
+      } else if (split) {
         GPX_RET(col_update(k + 1, 1, k, 1, false));
         GPX_RET(wait_for_t());
         GPX_RET(col_update(k + 2, 1, last_t + 1, npan2, true));
@@ -1048,6 +1116,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         GPX_RET(launch_gemm_nt(h, T, t));
         if (!attach || timed) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
         t_pending[(size_t)k] = 1;
+        trail_rec[(size_t)k].store(1, std::memory_order_release);
         t_idx = k; t_from = cf;
       }
       // behind the bulk update (Q's next column update waits for that one, not for this), two panels at a time:

@@ -573,11 +573,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
 // and apply A_{k+1,k+1} -= S S^T to their tile (gu: publishes to the counter potrf_diag(k+1) polls).  The second kernel's
 // launch -- ~2 us between the two even back to back on one stream -- becomes a flag round trip inside a launch whose
 // 16 workgroups are all resident (they never wait for a workgroup that is not: phase 1 waits only for potrf_diag).
+// Phase 0 (gz.K > 0, lower tiles only): one more update of the SAME diagonal block, whose operands are ready before W_k
+// is -- the previous panel's contribution -- applied while the kernel would otherwise sleep.  The thread that stores an
+// entry in phase 0 is the thread that loads it in phase 2 (same tile, same lane map): program order, no fence.
 template <int K>
-__global__ __launch_bounds__(256, 2) void chain_band_kernel(GemmArgs gs, GemmArgs gu) {
+__global__ __launch_bounds__(256, 2) void chain_band_kernel(GemmArgs gz, GemmArgs gs, GemmArgs gu) {
   __shared__ __attribute__((aligned(16))) double As[32 * (K / 2 + 4)];
   __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+  if (gz.K > 0 && n0 <= m0) {
+    onepass_body<K>(gz, m0, n0, As, Bs);
+    __syncthreads();   // the LDS image is reused by phase 1
+  }
   onepass_body<K>(gs, m0, n0, As, Bs);
   if (n0 > m0) return;   // strictly upper tile of the diagonal block
   onepass_body<K>(gu, m0, n0, As, Bs);
@@ -596,21 +603,27 @@ static void fill_args(GemmArgs& g, const GemmLaunch& L) {
 
 // S (nb x nb, L.N == L.M == L.K == nb) and the update of the diagonal block in one launch; both launches as the caller
 // would have issued them separately, S.signal / U.wait_flag pointing at the same zeroed counter
-int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch& S, const GemmLaunch& U) {
+int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch* Z, const GemmLaunch& S, const GemmLaunch& U) {
   const int64_t nb = S.K;
   if ((nb != 128 && nb != 64) || S.M != nb || S.N != nb || U.M != nb || U.N != nb || U.K != nb || !S.signal || U.wait_flag != S.signal ||
       U.wait_count != (unsigned)((nb / 32) * (nb / 32))) {
     gpx_set_error(h, "chain_band: contract violated");
     return GPX_ERR_ARG;
   }
-  GemmArgs gs, gu;
+  GemmArgs gz, gs, gu;
   fill_args(gs, S); fill_args(gu, U);
+  if (Z) {
+    if (Z->M != nb || Z->N != nb || Z->K != nb || Z->C != U.C || Z->signal || Z->wait_flag) { gpx_set_error(h, "chain_band: phase-0 contract violated"); return GPX_ERR_ARG; }
+    fill_args(gz, *Z);
+  } else {
+    fill_args(gz, U); gz.K = 0; gz.signal = nullptr; gz.wait_flag = nullptr;
+  }
 #ifdef GPX_TIMELINE
   gs.tl_id = g_tl_launch++; gu.tl_id = g_tl_launch++;
 #endif
   dim3 grid((unsigned)(nb / 32), (unsigned)(nb / 32));
-  if (nb == 128) hipExtLaunchKernelGGL((chain_band_kernel<128>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gs, gu);
-  else hipExtLaunchKernelGGL((chain_band_kernel<64>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gs, gu);
+  if (nb == 128) hipExtLaunchKernelGGL((chain_band_kernel<128>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gz, gs, gu);
+  else hipExtLaunchKernelGGL((chain_band_kernel<64>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gz, gs, gu);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

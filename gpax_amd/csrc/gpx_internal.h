@@ -95,7 +95,8 @@ struct GemmLaunch {
   int* wait_info = nullptr;   // device int set to -7 if the bounded wait gives up
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
-int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch& S, const GemmLaunch& U);   // the chain's two band kernels in one launch
+// the chain's two band kernels in one launch; Z (optional): an update of the same diagonal block applied first, before the wait for W_k
+int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch* Z, const GemmLaunch& S, const GemmLaunch& U);
 
 // Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda,
@@ -210,6 +211,7 @@ struct gpx_handle {
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 32;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 48;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int diag_band = 1;   // fused band kernel, ungrouped steps: panel k-1's update of block (k+1,k+1) is done by the band kernel of step k while it waits for potrf_diag(k)
   int border_side = 1; // split-panel schedule: k_cross / r / zero border rows are built on the panel stream, off the chain
   int fuse_band = 1;   // in-kernel hand-over schedule: S = A W_k^T and A -= S S^T in one launch
   int near_block = 1;  // grouped phases: the next group's columns are updated by Q in a launch of its own, the bulk launch starts behind them
