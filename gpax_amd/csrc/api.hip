@@ -312,6 +312,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_FUSE_BAND"))) h->fuse_band = atoi(env) != 0;
   if ((env = getenv("GPX_BORDER_SIDE"))) h->border_side = atoi(env) != 0;
   if ((env = getenv("GPX_DIAG_BAND"))) h->diag_band = atoi(env) != 0;
+  if ((env = getenv("GPX_LP_FLAG"))) h->lp_flag = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -390,6 +391,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "fuse_band")) { h->fuse_band = value != 0; return GPX_OK; }
   if (!strcmp(name, "border_side")) { h->border_side = value != 0; return GPX_OK; }
   if (!strcmp(name, "diag_band")) { h->diag_band = value != 0; return GPX_OK; }
+  if (!strcmp(name, "lp_flag")) { h->lp_flag = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -410,6 +412,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "fuse_band")) { *value = h->fuse_band; return GPX_OK; }
   if (!strcmp(name, "border_side")) { *value = h->border_side; return GPX_OK; }
   if (!strcmp(name, "diag_band")) { *value = h->diag_band; return GPX_OK; }
+  if (!strcmp(name, "lp_flag")) { *value = h->lp_flag; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -809,7 +812,11 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   const bool use_dib = fuse_band && h->diag_band != 0 && !kinv;
   std::vector<char> dib((size_t)nblk + 2, 0);
   std::vector<int64_t> band_t((size_t)nblk + 2, -1);
-  if (use_dib) {
+  // lp_flag: the last border panel (chain stream) is ordered behind the panel stream's last column update by a device
+  // counter that update's tiles raise (flagsS[nblk-1], otherwise unused) instead of a stream-level event wait in front
+  // of the last potrf_diag, which kept that kernel from starting resident (+17 us at the tail of every step)
+  bool lp_flag = false;
+  if (chain2 && !kinv) {
     const int64_t pm = h->pair_min, qm = h->quad_min;
     auto gsz = [&](int64_t left) -> int64_t { return (qm > 0 && left > qm) ? 4 : ((pm > 0 && left > pm) ? 2 : 1); };
     int64_t lt = -1, ge = -1, ti = -1, tf = nblk;
@@ -823,7 +830,8 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         if (gn >= 2) near = std::max<int64_t>(0, std::min<int64_t>(gn, nblk - (j + 3)));
       }
       const int64_t mr = rows - (j + 2) * nb, ncb = std::min<int64_t>(2, nblk - (j + 1));
-      if (mr > 0 && ncb > 1 && j - lt == 1) {
+      if (h->lp_flag && j == nblk - 2 && j - lt == 1 && mr > 0 && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) lp_flag = true;
+      if (use_dib && mr > 0 && ncb > 1 && j - lt == 1) {
         dib[(size_t)(j + 1)] = 1;
         band_t[(size_t)(j + 1)] = (ti >= 0 && j + 2 >= tf) ? ti : -1;
       }
@@ -848,7 +856,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     // packet behind it), else recorded right after it -- NOT after the two band kernels (measured 1.91 -> 2.12 ms
     // per N = 4096 step when the panel stream learns of W_k 12 us later)
     const bool need_w = rows - r0 > 0;
-    if (need_w && k + 1 >= nblk && !kinv && k >= 1) {
+    if (need_w && k + 1 >= nblk && !kinv && k >= 1 && !lp_flag) {
       // The last panel (below) reads the border rows of column k on THIS stream; their last writer is Q's column update
       // of step k-1.  Nothing else orders the two (potrf_diag(k) only waits for the band kernel of step k-1, which
       // waited for Q's step k-2): wait for it here, in front of potrf_diag, where it costs nothing -- that update is
@@ -875,6 +883,9 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       g.C = L + r0 * ld + c0; g.ldc = ld;
       g.M = rows - r0; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
       g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+      if (lp_flag && k >= 1) {   // its input rows were last written by the panel stream's column update of step k-1: wait for that update's tiles
+        g.wait_flag = flagsS + k; g.wait_count = (unsigned)((nb / 32) * ((rows - r0) / 32)); g.wait_info = h->d_info;
+      }
       prof_begin(h, P, GPX_STAGE_TRSM_PANEL, (double)g.M * nb * nb, 8.0 * (2.0 * g.M * nb + nb * nb));
       GPX_RET(launch_gemm_nt(h, P, g));
       prof_end(h, P);
@@ -1029,6 +1040,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       t.C = A + rr * ld + cfirst * nb; t.ldc = ld;
       t.M = mr; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
       t.lower = 1; t.row_off = rr; t.col_off = cfirst * nb; t.b_lower_tri = 0;
+      if (lp_flag && k == nblk - 2 && cfirst == nblk - 1) t.signal = flagsS + (nblk - 1);   // the last border panel waits for these tiles (chain stream)
       // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
       // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency
       t.small_tile = (h->la_rows > 0 && mr >= h->la_rows) ? 0 : 1;

@@ -182,6 +182,10 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  hardware-counter collection, inside a stream capture and under per-launch bracketing)
  *   "pair_min" / "quad_min"  group the bulk updates two / four panels at a time while more than this many block
  *                  columns remain; 0 = never (32 / 48)
+ *   "diag_band"    fused band kernel, ungrouped steps: the previous panel's update of the diagonal block is done by the band kernel
+ *                  itself while it waits for potrf_diag; the panel stream's update of column k+2 starts below that block (1)
+ *   "lp_flag"      the last border panel waits for the panel stream's last column update through a device counter instead
+ *                  of a stream-level event wait in front of the last potrf_diag (1)
  *   "border_side"  split-panel schedule: the border (k_cross rows, r row) is built on the panel stream, whose first kernel is its
  *                  first reader, instead of on the chain stream in front of potrf_diag(0) (1)
  *   "fuse_band"    in-kernel hand-over schedule: the chain's two band kernels (S = A W_k^T, A -= S S^T) run as ONE launch
