@@ -209,8 +209,8 @@ struct gpx_handle {
   bool nb_auto = true;   // no explicit "nb" option: 64 for n <= 64 (potrf_diag<64> runs 12 us, <128> 29 us), else 128
   int lookahead = 1;
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
-  int pair_min = 32;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
-  int quad_min = 48;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int pair_min = 28;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
+  int quad_min = 40;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
   int lp_flag = 1;     // the last border panel waits for the panel stream's last column update through a device counter (0: a stream-level event wait in front of the last potrf_diag)
   int diag_band = 1;   // fused band kernel, ungrouped steps: panel k-1's update of block (k+1,k+1) is done by the band kernel of step k while it waits for potrf_diag(k)
   int border_side = 1; // split-panel schedule: k_cross / r / zero border rows are built on the panel stream, off the chain

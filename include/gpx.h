@@ -181,7 +181,7 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  resident and sleeps on a device flag, 2 = so does S = A W_k^T (2; falls back to 0 under
  *                  hardware-counter collection, inside a stream capture and under per-launch bracketing)
  *   "pair_min" / "quad_min"  group the bulk updates two / four panels at a time while more than this many block
- *                  columns remain; 0 = never (32 / 48)
+ *                  columns remain; 0 = never (28 / 40)
  *   "diag_band"    fused band kernel, ungrouped steps: the previous panel's update of the diagonal block is done by the band kernel
  *                  itself while it waits for potrf_diag; the panel stream's update of column k+2 starts below that block (1)
  *   "lp_flag"      the last border panel waits for the panel stream's last column update through a device counter instead

@@ -213,6 +213,45 @@ def test_lookahead_schedules_are_deterministic(core, depth):
     assert np.abs(l0 - orc.cholesky_lower(orc.rbf(x, x, 1.0, 1.0, p["k_noise"], 1e-6))).max() <= TOL_L
 
 
+@pytest.mark.parametrize("off", [(), ("fuse_band",), ("diag_band",), ("lp_flag",), ("border_side",), ("near_block",),
+                                 ("fuse_band", "lp_flag", "border_side", "near_block"), ("resident",)])
+@pytest.mark.parametrize("n,m,grouped", [(200, 250, False), (1100, 90, False), (1333, 77, True)])
+def test_schedule_switches_are_bit_identical(core, off, n, m, grouped):
+    """Every hand-over refinement of the split-panel schedule (one launch for the band, the diagonal block in the band
+    kernel, the counter-ordered last panel, the border on the panel stream, the near block of grouped phases, in-kernel
+    hand-overs at all) only moves WHEN a kernel runs: with any of them switched off the factor path must return the very
+    same bits -- and the oracle's numbers."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, y, xn, p = orc.synthetic_problem(n, 4, m, seed=n)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    if grouped:
+        core.set_option("nb", 64)
+        core.set_option("pair_min", 6)
+        core.set_option("quad_min", 12)
+    core.set_train(x)
+    core.set_test(xn)
+    try:
+        ref = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
+        for name in off:
+            core.set_option(name, 0)
+        for _ in range(3):
+            got = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
+            assert got[0] == ref[0] == 0 and got[1] == ref[1]
+            assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    finally:
+        for name in ("fuse_band", "diag_band", "lp_flag", "border_side", "near_block"):
+            core.set_option(name, 1)
+        core.set_option("resident", 2)
+        core.set_option("nb", 0)
+        core.set_option("pair_min", 28)
+        core.set_option("quad_min", 40)
+    logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, p)
+    assert abs(ref[1] - logp_ref) <= 1e-10 * abs(logp_ref)
+    assert np.abs(ref[2] - mean_ref).max() <= 1e-8 and np.abs(ref[3] - var_ref).max() <= 1e-8
+
+
 @pytest.mark.parametrize("pair_min,quad_min", [(0, 0), (1, 0), (6, 0), (13, 0), (1, 1), (4, 10), (0, 7)])
 def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
     """The split-panel schedule groups the bulk updates (the last 2 or 4 panels in one K = 2 nb / 4 nb pass)
@@ -231,8 +270,8 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
     _, _, l = core.fit_factor(prm, want_l=True)
     info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(77), 0.0)
     core.set_option("nb", 0)   # automatic again
-    core.set_option("pair_min", 32)
-    core.set_option("quad_min", 48)
+    core.set_option("pair_min", 28)
+    core.set_option("quad_min", 40)
     assert info == 0
     k_ref = orc.rbf(x, x, p["k_scale"], p["k_length"], p["k_noise"], p["k_jitter"])
     assert np.abs(l - orc.cholesky_lower(k_ref)).max() <= TOL_L
@@ -274,7 +313,7 @@ def test_grouped_schedule_at_default_thresholds_matches_the_oracle(core):
 
     x, y, xn, p = orc.synthetic_problem(6300, 8, 257, seed=41)
     prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
-    assert core.get_option("pair_min") == 32 and core.get_option("quad_min") == 48 and core.get_option("nb") == 128
+    assert core.get_option("pair_min") == 28 and core.get_option("quad_min") == 40 and core.get_option("nb") == 128
     core.set_train(x)
     core.set_test(xn)
     info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(257), 0.0)
