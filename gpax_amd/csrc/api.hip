@@ -79,7 +79,7 @@ static int ensure(gpx_handle* h, T** p, int64_t* cap, int64_t count) {
 
 static hipEvent_t prof_event(gpx_handle* h) {
   if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
-  hipEvent_t e; (void)hipEventCreate(&e); return e;
+  hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;   // timing on; device-scope release only, like the hand-over events
 }
 
 // mode 1: every launch is bracketed; mode 2 (coarse): only the whole step, the gram build and the epilogue --
@@ -841,6 +841,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       }
     }
   }
+  std::vector<hipEvent_t> tev((size_t)nblk, nullptr);   // hand-over event of the bulk launch of step k (set when it is launched)
   std::unique_ptr<std::atomic<int>[]> trail_rec(new std::atomic<int>[(size_t)nblk]);
   for (int64_t k = 0; k < nblk; ++k) trail_rec[(size_t)k].store(0);
 
@@ -919,7 +920,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       if (phase0) {
         if (band_t[(size_t)k] >= 0) {   // the bulk launch that last wrote the block
           if (!await(trail_rec[(size_t)band_t[(size_t)k]])) return GPX_ERR_HIP;
-          GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_trail[(size_t)band_t[(size_t)k]], 0));
+          GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)band_t[(size_t)k]], 0));
         }
         z.A = L + r0 * ld + (k - 1) * nb; z.lda = ld;
         z.B = z.A; z.ldb = ld;
@@ -1056,7 +1057,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     if (mr > 0) {
       auto wait_for_t = [&]() -> int {   // column k+2 was last written by the bulk launch of step t_idx -- if it lies in its range
         if (t_idx >= 0 && k + 2 >= t_from && t_idx != q_waited_t && t_pending[(size_t)t_idx]) {
-          GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)t_idx], 0));
+          GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, tev[(size_t)t_idx], 0));
           q_waited_t = t_idx;
         }
         return GPX_OK;
@@ -1091,7 +1092,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     // Q: the near block (columns k+3 .. k+2+near_cols, panels last_t+1 .. k), behind the event the chain waits for
     if (near_cols > 0) {
       if (t_idx >= 0 && t_idx != q_waited_t && t_pending[(size_t)t_idx]) {   // those columns were last written by the previous bulk launch
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)t_idx], 0));
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, tev[(size_t)t_idx], 0));
         q_waited_t = t_idx;
       }
       const int64_t kfirst = last_t + 1, npan = k - last_t;
@@ -1124,9 +1125,12 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
         // profiled: the kernel's own dispatch timestamps (what rocprofv3 reports), the hand-over event recorded behind it
         const bool timed = prof_pair(h, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K),
                                      &t.start_event, &t.stop_event);
+        // timed (profile mode 3): the timing stop event, attached to the kernel's own dispatch, IS the hand-over event -- a
+        // second record behind the launch delayed every consumer of the bulk update and stretched the measured step by 10 %
         if (attach && !timed) t.stop_event = h->ev_trail[(size_t)k];
+        tev[(size_t)k] = (attach && timed) ? t.stop_event : h->ev_trail[(size_t)k];
         GPX_RET(launch_gemm_nt(h, T, t));
-        if (!attach || timed) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
+        if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
         t_pending[(size_t)k] = 1;
         trail_rec[(size_t)k].store(1, std::memory_order_release);
         t_idx = k; t_from = cf;
