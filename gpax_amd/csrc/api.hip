@@ -313,6 +313,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_BORDER_SIDE"))) h->border_side = atoi(env) != 0;
   if ((env = getenv("GPX_DIAG_BAND"))) h->diag_band = atoi(env) != 0;
   if ((env = getenv("GPX_LP_FLAG"))) h->lp_flag = atoi(env) != 0;
+  if ((env = getenv("GPX_EPI_SPLIT"))) h->epi_split = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -349,6 +350,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   if (h->ev_chain2) (void)hipEventDestroy(h->ev_chain2);
   if (h->ev_build) (void)hipEventDestroy(h->ev_build);
   if (h->d_flags) (void)hipFree(h->d_flags);
+  if (h->d_epart) (void)hipFree(h->d_epart);
   if (h->s_trail) (void)hipStreamDestroy(h->s_trail);
   if (h->s_far) (void)hipStreamDestroy(h->s_far);
   delete h;
@@ -392,6 +394,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "border_side")) { h->border_side = value != 0; return GPX_OK; }
   if (!strcmp(name, "diag_band")) { h->diag_band = value != 0; return GPX_OK; }
   if (!strcmp(name, "lp_flag")) { h->lp_flag = value != 0; return GPX_OK; }
+  if (!strcmp(name, "epi_split")) { h->epi_split = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -413,6 +416,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "border_side")) { *value = h->border_side; return GPX_OK; }
   if (!strcmp(name, "diag_band")) { *value = h->diag_band; return GPX_OK; }
   if (!strcmp(name, "lp_flag")) { *value = h->lp_flag; return GPX_OK; }
+  if (!strcmp(name, "epi_split")) { *value = h->epi_split; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -997,6 +1001,12 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       GPX_RET(launch_gemm_nt(h, Q, g));
       prof_end(h, Q);
       if (t_needs && !attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
+      // every block column but the last is final now (V^T, z and the diagonal of L): their share of the epilogue's
+      // reductions runs here, on the panel stream, beside the last potrf_diag instead of behind the last panel
+      if (h->epi && k == nblk - 2 && nblk >= 3 && h->d_epart) {
+        GPX_RET(launch_epilogue_partial(h, Q, *h->epi, (nblk - 1) * nb, h->d_epart));
+        h->epi_split_col = (nblk - 1) * nb;
+      }
     }
     // K^-1 += U_{:,j} U_{:,j}^T for the panels j = last_t+1 .. k that are complete now (gradient path): rank-(npan nb)
     // update of the leading (k+1) nb square, lower tiles, on T.  Small while the bulk updates are big and growing as
@@ -1698,7 +1708,6 @@ extern "C" int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* c
 static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
   const int64_t m = fp.m_rows;
   hipStream_t s = h->s_main;
-  GPX_RET(factor_enqueue(h, fp, nullptr));
   EpilogueLaunch e;
   e.L = h->d_L; e.ld = h->ld; e.n = h->n; e.z = h->d_L + (h->npad + m) * h->ld;
   e.vt = h->d_L + h->npad * h->ld; e.vt_ld = h->ld; e.m = m;
@@ -1706,9 +1715,20 @@ static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
   e.prior_diag = 0.0; e.dev_prior_diag = h->d_hyp + 2 * h->d + 3;
   e.scal = h->d_scal; e.mean = h->d_mean; e.var = h->d_var;
   e.z_copy = h->d_z; e.npad = h->npad;   // keep z for later posterior calls against the cached factor
+  // split epilogue (split-panel schedule, three block columns or more): see side() in factor_loop_split
+  h->epi = nullptr; h->epi_split_col = 0;
+  if (h->epi_split && !h->in_capture && h->prof_mode != 1 && h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= 3) {
+    GPX_RET(ensure(h, &h->d_epart, &h->epart_cap, 2 + 2 * std::max<int64_t>(m, 1)));
+    h->epi = &e;
+  }
+  const int frc = factor_enqueue(h, fp, nullptr);
+  h->epi = nullptr;
+  GPX_RET(frc);
   prof_begin(h, s, GPX_STAGE_EPILOGUE, 4.0 * (m + 1.0) * h->n, 8.0 * (m + 2.0) * h->n);
-  GPX_RET(launch_epilogue(h, s, e));
+  if (h->epi_split_col > 0) GPX_RET(launch_epilogue_final(h, s, e, h->epi_split_col, h->d_epart));
+  else GPX_RET(launch_epilogue(h, s, e));
   prof_end(h, s);
+  h->epi_split_col = 0;
   return GPX_OK;
 }
 

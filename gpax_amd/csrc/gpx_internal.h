@@ -133,6 +133,9 @@ struct EpilogueLaunch {
   double* z_copy = nullptr; int64_t npad = 0;   // also copy z[0:npad) here (the handle's z for later posterior calls)
 };
 int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
+// split epilogue: columns [0, c1) early as partial sums (part: 2 + 2 m doubles), then [c1, n) + part, finalised
+int launch_epilogue_partial(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c1, double* part);
+int launch_epilogue_final(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c0, double* part);
 
 // post_reduce only (mean / variance of m rows of V^T against z)
 int launch_post_reduce(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
@@ -198,6 +201,9 @@ struct gpx_handle {
   unsigned* d_flags = nullptr; int64_t flags_cap = 0;
   bool flags_clean = false;   // the flags were cleared by the gram launch of this call (no memset needed)   // per-step tile counters of the resident start
   hipEvent_t ev_chain2 = nullptr;
+  const EpilogueLaunch* epi = nullptr;   // set by fit_predict around factor_enqueue: the split-panel loop may launch the early half
+  int64_t epi_split_col = 0;             // columns [0, epi_split_col) were reduced early into d_epart (0: not split)
+  double* d_epart = nullptr; int64_t epart_cap = 0;
   hipEvent_t ev_build = nullptr;   // K built on the chain stream -> the border rows are built on the panel stream
   int resident = 2;                // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
                                    // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag)
@@ -211,6 +217,7 @@ struct gpx_handle {
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 28;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 40;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int epi_split = 1;   // fit+predict: the posterior / log-marginal reductions over all block columns but the last run on the panel stream beside the last potrf_diag
   int lp_flag = 1;     // the last border panel waits for the panel stream's last column update through a device counter (0: a stream-level event wait in front of the last potrf_diag)
   int diag_band = 1;   // fused band kernel, ungrouped steps: panel k-1's update of block (k+1,k+1) is done by the band kernel of step k while it waits for potrf_diag(k)
   int border_side = 1; // split-panel schedule: k_cross / r / zero border rows are built on the panel stream, off the chain

@@ -53,42 +53,67 @@ __global__ __launch_bounds__(256) void post_reduce_kernel(const double* vt, int6
 // Fused epilogue: block 0 = the log-marginal pieces (and, on request, the copy of z into the handle's z
 // buffer for later posterior calls), blocks 1..m = one test row each.  One launch instead of a device copy and
 // two kernels at the tail of every fit+predict step.
+// Column range [c0, c1) and `mode`: 0 = everything in one launch (c0 = 0, c1 = n); 1 = PARTIAL sums over the range,
+// written raw to part[] = [logdet, quad, dot(m), ss(m)] -- launched on the panel stream as soon as all block columns
+// but the last are final, i.e. beside the last potrf_diag; 2 = FINAL: the rest of the range plus part[], finalised.
 __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t ld, int64_t n, const double* z,
                                                       double* z_copy, int64_t npad, double* scal, const double* vt,
                                                       int64_t vt_ld, const double* m_new, double prior_diag,
-                                                      const double* dev_prior_diag, double* mean, double* var) {
+                                                      const double* dev_prior_diag, double* mean, double* var,
+                                                      int64_t c0, int64_t c1, double* part, int64_t m, int mode) {
   if (blockIdx.x == 0) {
     double s1 = 0.0, s2 = 0.0;
-    for (int64_t i = threadIdx.x; i < npad; i += 256) {
+    if (mode != 1 && z_copy)
+      for (int64_t i = threadIdx.x; i < npad; i += 256) z_copy[i] = z ? z[i] : 0.0;
+    for (int64_t i = c0 + threadIdx.x; i < c1; i += 256) {
       const double v = z ? z[i] : 0.0;
-      if (z_copy) z_copy[i] = v;
       if (i < n) { s1 += log(L[i * ld + i]); s2 = fma(v, v, s2); }
     }
     block_sum2<256>(s1, s2);
-    if (threadIdx.x == 0) { scal[0] = s1; scal[1] = s2; }
+    if (threadIdx.x == 0) {
+      if (mode == 1) { part[0] = s1; part[1] = s2; }
+      else if (mode == 2) { scal[0] = part[0] + s1; scal[1] = part[1] + s2; }
+      else { scal[0] = s1; scal[1] = s2; }
+    }
     return;
   }
   const int64_t row = blockIdx.x - 1;
   const double* v = vt + row * vt_ld;
   double dot = 0.0, ss = 0.0;
-  for (int64_t c = threadIdx.x; c < n; c += 256) {
+  const int64_t cend = c1 < n ? c1 : n;
+  for (int64_t c = c0 + threadIdx.x; c < cend; c += 256) {
     const double x = v[c];
     dot = fma(x, z[c], dot);
     ss = fma(x, x, ss);
   }
   block_sum2<256>(dot, ss);
   if (threadIdx.x == 0) {
+    if (mode == 1) { part[2 + row] = dot; part[2 + m + row] = ss; return; }
+    if (mode == 2) { dot += part[2 + row]; ss += part[2 + m + row]; }
     mean[row] = (m_new ? m_new[row] : 0.0) + dot;
     var[row] = (dev_prior_diag ? dev_prior_diag[0] : prior_diag) - ss;
   }
 }
 
-int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
+static int launch_epilogue_range(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c0, int64_t c1, double* part, int mode) {
   const int64_t rows = (e.m > 0 && e.z) ? e.m : 0;
   hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(rows + 1)), dim3(256), 0, s, e.L, e.ld, e.n, e.z, e.z_copy,
-                     e.z_copy ? e.npad : e.n, e.scal, e.vt, e.vt_ld, e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var);
+                     e.z_copy ? e.npad : e.n, e.scal, e.vt, e.vt_ld, e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var,
+                     c0, c1, part, rows, mode);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
+}
+
+int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {
+  return launch_epilogue_range(h, s, e, 0, e.z_copy ? e.npad : e.n, nullptr, 0);
+}
+
+// the two halves of a split epilogue: columns [0, c1) early (partial sums into part[2 + 2m]), [c1, n) + part at the end
+int launch_epilogue_partial(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c1, double* part) {
+  return launch_epilogue_range(h, s, e, 0, c1, part, 1);
+}
+int launch_epilogue_final(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c0, double* part) {
+  return launch_epilogue_range(h, s, e, c0, e.z_copy ? e.npad : e.n, part, 2);
 }
 
 int launch_post_reduce(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e) {

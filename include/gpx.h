@@ -184,6 +184,9 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  columns remain; 0 = never (28 / 40)
  *   "diag_band"    fused band kernel, ungrouped steps: the previous panel's update of the diagonal block is done by the band kernel
  *                  itself while it waits for potrf_diag; the panel stream's update of column k+2 starts below that block (1)
+ *   "epi_split"    fit+predict: the posterior / log-marginal reductions over all block columns but the last are taken on the
+ *                  panel stream as soon as those columns are final (beside the last potrf_diag); the epilogue behind the last
+ *                  panel only adds the last block column (1)
  *   "lp_flag"      the last border panel waits for the panel stream's last column update through a device counter instead
  *                  of a stream-level event wait in front of the last potrf_diag (1)
  *   "border_side"  split-panel schedule: the border (k_cross rows, r row) is built on the panel stream, whose first kernel is its
