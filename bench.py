@@ -194,6 +194,7 @@ def main():
                     help="draws: independent hyper-parameter draws per rank (default, weak scaling); "
                          "dist: ONE factorisation row-block-cyclic over the ranks with RCCL panel broadcasts (config C4, strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the N = 1k..32k size sweep reported beside the headline number (N=1 only, ~10 s)")
     ap.add_argument("--stages", action="store_true", help="add a third pass with every launch bracketed: per-stage milliseconds")
     ap.add_argument("--cpu-reps", type=int, default=3)
     ap.add_argument("--dist-n", type=int, default=32768, help="world size > 1: also run config C4 (one factorisation over all ranks, "
@@ -346,6 +347,32 @@ def main():
             out["ms_per_step_all_bracketed"] = (time.perf_counter() - t2) / args.steps * 1e3
             out["stage_ms_per_step"] = {gpax_amd._lib.STAGE_NAMES[i]: core.profile_get(i)["ms"] / args.steps for i in range(8)}
             core.profile_mode(0)
+
+        if not args.no_sweep and world == 1 and args.n == 4096:
+            # ---- the other sizes BASELINE.json's metric is quoted on (N in 1k..32k, same d and M), a few steps each,
+            # outside the headline region: points/s and the whole step's fp64 rate (N^3/3 + N^2 (M+1) flops)
+            sweep = []
+            for ns in (1024, 2048, 8192, 16384, 32768):
+                xs, ys, xns = synthetic_problem(ns, d, m, seed=0)
+                core.set_train(xs)
+                core.set_test(xns)
+                core.set_targets(ys - 1.0, np.ones(m))
+                reps = 20 if ns <= 2048 else (5 if ns <= 8192 else 2)
+                for _ in range(2):
+                    step()
+                sync()
+                t3 = time.perf_counter()
+                for _ in range(reps):
+                    info_s, logp_s, mean_s, var_s = step()
+                sync()
+                ms = (time.perf_counter() - t3) / reps * 1e3
+                sweep.append({"n": ns, "ms_per_step": ms, "points_per_s": ns / (ms * 1e-3),
+                              "step_tflops": (ns ** 3 / 3 + ns * ns * (m + 1)) / (ms * 1e-3) * 1e-12,
+                              "ok": bool(info_s == 0 and np.isfinite(logp_s) and (var_s > 0).all())})
+            out["sweep"] = sweep
+            core.set_train(x)   # back to the headline problem for the CPU comparison below
+            core.set_test(x_new)
+            core.set_targets(y - 1.0, np.ones(m))
 
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
             # ---- CPU baseline: the oracle (NumPy/SciPy port of the reference formulae; the reference's

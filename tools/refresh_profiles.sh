@@ -9,11 +9,11 @@ rm -rf $OUT; mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"; tail -c 300 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $R/bench.py --no-cpu-baseline --no-sweep > $OUT/stats_bench.json 2> $OUT/stats.err
 echo "kernel stats done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
-rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/pmc_mfma -o p -- python3 $R/bench.py --no-cpu-baseline --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_mfma.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3 $R/bench.py --no-cpu-baseline --no-sweep --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $R/bench.py --no-cpu-baseline --no-sweep --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/pmc_mfma -o p -- python3 $R/bench.py --no-cpu-baseline --no-sweep --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_mfma.err
 echo "pmc done"
 cd $R
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/traffic.json $OUT/pmc_mfma > /dev/null
