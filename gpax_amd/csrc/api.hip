@@ -1055,6 +1055,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
       // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency
       t.small_tile = (h->la_rows > 0 && mr >= h->la_rows) ? 0 : 1;
+      t.role = 1;
       double entries = 0.0;
       for (int64_t c = cfirst; c < cfirst + ncol; ++c)
         entries += (c * nb >= rr) ? (double)nb * (nb + 1) / 2.0 + (double)(mr - nb) * nb : (double)mr * nb;
@@ -1112,7 +1113,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       t.B = L + br * ld + kfirst * nb; t.ldb = ld;
       t.C = A + br * ld + br; t.ldc = ld;
       t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-      t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
+      t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0; t.role = 1;
       const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
       prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
       GPX_RET(launch_gemm_nt(h, Q, t));

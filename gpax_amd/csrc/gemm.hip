@@ -131,7 +131,9 @@ __device__ __forceinline__ bool tile_from_block(const GemmArgs& g, int64_t& ti, 
   return ti < g.map_nti && tj < g.map_ntj && tj <= ti;
 }
 
-template <int BM, int BN, bool HASC>   // HASC: beta != 0 (compile-time, so that the C requests are straight-line code)
+// ROLE only names the instantiation (0: the bulk trailing update, 1: look-ahead column updates and near blocks on the panel
+// stream): profilers then report the roofline kernel's launches apart from the small ones that share its code
+template <int BM, int BN, bool HASC, int ROLE = 0>   // HASC: beta != 0 (compile-time, so that the C requests are straight-line code)
 // (256, 2): a register budget of 256 makes hipcc keep the accumulators in VGPRs.  With the default budget it
 // puts them in AGPRs, and v_mfma_f64_16x16x4_f64 with an AGPR accumulator issues every ~100 cycles instead of
 // 64 (tools/peaks: 49 vs 78 TFLOP/s) -- the single largest factor in this kernel's throughput.
@@ -680,7 +682,8 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     const int64_t nti = L.M / 64, ntj = L.N / 64;
     g.map_S = -1; g.map_nti = nti; g.map_ntj = ntj;
     const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
-    if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    if (L.beta != 0.0 && L.role == 1) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true, 1>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    else if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
     else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
     GPX_HIP_CHECK(h, hipGetLastError());
     return GPX_OK;
@@ -711,6 +714,7 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   else if (L.small_tile && L.K == 64) hipExtLaunchKernelGGL((gemm_nt_onepass_kernel<64>), grid, dim3(256), 0, s, sb, se, 0, g);
   else if (L.small_tile && L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32, true>), grid, dim3(256), 0, s, sb, se, 0, g);
   else if (L.small_tile) hipExtLaunchKernelGGL((gemm_nt_kernel<32, 32, false>), grid, dim3(256), 0, s, sb, se, 0, g);
+  else if (L.beta != 0.0 && L.role == 1) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true, 1>), grid, dim3(256), 0, s, sb, se, 0, g);
   else if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), grid, dim3(256), 0, s, sb, se, 0, g);
   else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), grid, dim3(256), 0, s, sb, se, 0, g);
   GPX_HIP_CHECK(h, hipGetLastError());

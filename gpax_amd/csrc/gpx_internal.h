@@ -79,6 +79,7 @@ struct GemmLaunch {
   int64_t row_off, col_off;
   int b_lower_tri;      // B is lower triangular (B[n][k] = 0 for k > n): skip dead K
   int small_tile;       // 1: 32x32 workgroup tiles (latency path), 0: 64x64 (throughput path)
+  int role = 0;         // 64x64 path: 1 = look-ahead / near-block launch (a separately named instantiation of the same kernel)
   int variant = 0;      // 64x64 path: 0 = one workgroup per tile, 1 = persistent tile-pipelined kernel
   int cyc_P = 1, cyc_r = 0, cyc_nb = 128;   // block-cyclic local->global row map for the `lower` test (distributed path)
   int a_upper_tri = 0;  // A[m][k] = 0 for k < m: skip the dead K range below each tile's first row (64x64 path)
@@ -224,7 +225,7 @@ struct gpx_handle {
   int fuse_band = 1;   // in-kernel hand-over schedule: S = A W_k^T and A -= S S^T in one launch
   int near_block = 1;  // grouped phases: the next group's columns are updated by Q in a launch of its own, the bulk launch starts behind them
   int col_split = 0;   // the two look-ahead columns are updated by separate kernels while at least this many block columns are left to the bulk update; 0 = never
-  int la_rows = 6144;  // look-ahead column updates use 64x64 tiles while at least this many rows remain below (-1 % at N = 8192/16384; N = 4096 never gets there); 0 = never
+  int la_rows = 3072;  // look-ahead column updates use 64x64 tiles while at least this many rows remain below (-1 % at N = 4096/8192); 0 = never
   int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
 
   // resident inputs

@@ -196,7 +196,7 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *   "near_block"   grouped phases: at a group end the next group's block columns are updated by the panel stream in a
  *                  launch of its own and the bulk launch starts behind them, so the next group's chain runs while the bulk
  *                  launch does (1)
- *   "la_rows"      look-ahead column updates run on 64x64 tiles while at least this many rows remain below them; 0 = never (6144)
+ *   "la_rows"      look-ahead column updates run on 64x64 tiles while at least this many rows remain below them; 0 = never (3072)
  *   "col_split"    the two look-ahead columns are updated by separate kernels (only column k+2 behind the wait for the
  *                  bulk update) while at least this many block columns are left to the bulk update; 0 = never (0)
  *   "host_threads" 2 = the panel / bulk streams are fed by a second host thread (1)

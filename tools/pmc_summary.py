@@ -15,7 +15,7 @@ def main(fetch_dir, write_dir, out_json, mfma_dir=None):
     write = per_kernel(write_dir + "/**/*counter_collection.csv", "WRITE_SIZE")
     mfma = per_kernel(mfma_dir + "/**/*counter_collection.csv", "MfmaUtil") if mfma_dir else {}
     res = {}
-    for label, match in (("gram", "gram_kernel"), ("trailing_update", "gemm_nt_kernel<64, 64"), ("potrf_diag", "potrf_diag_kernel"), ("panel_gemm", "gemm_nt_onepass_kernel")):
+    for label, match in (("gram", "gram_kernel"), ("trailing_update", "gemm_nt_kernel<64, 64, true, 0>"), ("potrf_diag", "potrf_diag_kernel"), ("panel_gemm", "gemm_nt_onepass_kernel")):
         f = [v for k, vs in fetch.items() if match in k for _, v in vs]
         w = [v for k, vs in write.items() if match in k for _, v in vs]
         if not f or not w:
