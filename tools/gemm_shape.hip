@@ -28,6 +28,25 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e0)); for (int r = 0; r < 5; ++r) go(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 5;
     printf("M=%lld N=%lld K=%lld: %.1f us  %.1f TFLOP/s\n", (long long)M, (long long)N, (long long)K, ms * 1e3, 2.0 * entries * K / ms * 1e-9);
+    if (getenv("GAPTEST")) {   // what sits between consecutive launches on one stream: nothing / a satisfied event wait / an attached stop event
+      hipStream_t st, other; int lo, hi; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo)); CK(hipStreamCreateWithPriority(&other, hipStreamNonBlocking, hi));
+      hipEvent_t done[16], evs[16];
+      for (int i = 0; i < 16; ++i) { CK(hipEventCreateWithFlags(&done[i], hipEventDisableTiming | hipEventDisableSystemFence)); CK(hipEventCreateWithFlags(&evs[i], hipEventDisableTiming | hipEventDisableSystemFence)); CK(hipEventRecord(done[i], other)); }
+      CK(hipDeviceSynchronize());
+      for (int mode = 0; mode < 4; ++mode) {
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < 10; ++r) {
+          if (mode == 1 || mode == 3) CK(hipStreamWaitEvent(st, done[r], 0));
+          GemmLaunch u = t; u.stop_event = (mode >= 2) ? evs[r] : nullptr;
+          launch_gemm_nt(nullptr, st, u);
+        }
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float m2; CK(hipEventElapsedTime(&m2, e0, e1));
+        printf("   10 launches on a low-priority stream, %s: %.1f us per launch\n",
+               mode == 0 ? "nothing between" : mode == 1 ? "a satisfied event wait before each" : mode == 2 ? "a stop event attached to each" : "both", m2 * 100.0);
+      }
+    }
   }
   return 0;
 }
