@@ -464,3 +464,23 @@ def test_full_size_properties_c4_one_gpu(core):
     prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
     core.set_option("nb", 0)
     _solve_identity(core, 0, x, y - 1.0, prm, float(p["k_noise"][0] + p["k_jitter"][0]), 400, m, seed=8)
+
+
+@pytest.mark.parametrize("n,m,d,kind", [(129, 1, 2, 0), (200, 3200, 3, 0), (257, 5, 1, 1), (385, 3300, 4, 0), (256, 128, 2, 2),
+                                        (640, 129, 8, 1), (1025, 1, 3, 0), (130, 6500, 2, 0)])
+def test_edge_shapes_of_the_split_schedule(core, n, m, d, kind):
+    """Shapes at the edges of the schedule's special cases: two and three block columns, one test point, a border taller
+    than the look-ahead tile switch (so that the last panel falls back to the stream-level wait), a ragged last block --
+    three calls each (the second and third reuse every buffer, flag and event)."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, y, xn, p = orc.synthetic_problem(n, d, m, seed=n + m, kind=kind)
+    prm = gpax_amd.make_params(kind, p["k_scale"], p["k_length"], p.get("k_period"), p["k_noise"], p["k_jitter"])
+    core.set_train(x)
+    core.set_test(xn)
+    logp_ref, mean_ref, var_ref = orc.fit_predict(kind, x, y, xn, p)
+    for _ in range(3):
+        info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
+        assert info == 0 and abs(logp - logp_ref) <= 1e-10 * abs(logp_ref)
+        assert np.abs(mean - mean_ref).max() <= 1e-8 and np.abs(var - var_ref).max() <= 1e-8
