@@ -20,7 +20,6 @@ Deviations from the reference, on purpose:
 from __future__ import annotations
 
 import math
-from copy import deepcopy
 
 import numpy as np
 
@@ -173,7 +172,7 @@ class GaussianProcess:
         )
 
     def _split(self, params):
-        params = deepcopy(params)
+        params = dict(params)   # the values are only read (a deepcopy here cost 13 us per NUTS gradient call)
         m_params = {k: v for k, v in params.items() if "m_" in k}  # substring filters, gpax/gp.py:230-231
         k_params = {k: v for k, v in params.items() if "k_" in k}
         k_noise = k_params.pop("k_noise")
@@ -451,11 +450,15 @@ class _ParamSpace:
                 x, dxdu, gterm = dist.grad_terms(uu)
                 _, lj = dist.from_unconstrained(uu)
                 params[name] = np.asarray(x, dtype=np.float64)
-                log_prior += float(np.sum(dist.log_prob(x)) + np.sum(lj))
+                log_prior += float(np.asarray(dist.log_prob(x)).sum() + np.asarray(lj).sum())
                 dx[o : o + plate], g_prior[o : o + plate] = dxdu, gterm
                 o += plate
-        if not np.isfinite(log_prior) or not all(np.all(np.isfinite(v)) and np.all(np.abs(v) < 1e150) for v in params.values()):
+        if not math.isfinite(log_prior):
             return -np.inf, np.zeros(self.dim)
+        for v in params.values():   # (ndarray methods: the np.all / np.isfinite wrappers cost 20 us per call here)
+            a = np.asarray(v, dtype=np.float64)
+            if not (np.isfinite(a).all() and (np.abs(a) < 1e150).all()):
+                return -np.inf, np.zeros(self.dim)
         logp, grads = gp.log_marginal_and_grad(params)
         val = logp + log_prior
         if not np.isfinite(val):
