@@ -314,6 +314,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_DIAG_BAND"))) h->diag_band = atoi(env) != 0;
   if ((env = getenv("GPX_LP_FLAG"))) h->lp_flag = atoi(env) != 0;
   if ((env = getenv("GPX_EPI_SPLIT"))) h->epi_split = atoi(env) != 0;
+  if ((env = getenv("GPX_POTRF_PERSIST"))) h->potrf_persist = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -395,6 +396,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "diag_band")) { h->diag_band = value != 0; return GPX_OK; }
   if (!strcmp(name, "lp_flag")) { h->lp_flag = value != 0; return GPX_OK; }
   if (!strcmp(name, "epi_split")) { h->epi_split = value != 0; return GPX_OK; }
+  if (!strcmp(name, "potrf_persist")) { h->potrf_persist = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -417,6 +419,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "diag_band")) { *value = h->diag_band; return GPX_OK; }
   if (!strcmp(name, "lp_flag")) { *value = h->lp_flag; return GPX_OK; }
   if (!strcmp(name, "epi_split")) { *value = h->epi_split; return GPX_OK; }
+  if (!strcmp(name, "potrf_persist")) { *value = h->potrf_persist; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -776,6 +779,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
   unsigned* flagsW = h->d_flags + nblk;     // [k]: W_k published (S = A W_k^T of step k waits)
   unsigned* flagsS = h->d_flags + 2 * nblk; // [k]: tiles of S published (fused band kernel: its second phase waits)
   const bool fuse_band = chain2 && h->fuse_band != 0;
+  const bool persist = chain2 && h->potrf_persist != 0 && h->kinv_U == nullptr && tri_base < 0;   // ONE potrf_diag launch for all blocks
   GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
   GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
@@ -872,12 +876,17 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
 #endif
     }
-    prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
-    GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
-                              h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr,
-                              (resident && k >= 1) ? flagsU + (k - 1) : nullptr, n_signal,
-                              (chain2 && need_w && k + 1 < nblk) ? flagsW + k : nullptr));
-    prof_end(h, P);
+    if (persist) {
+      // every diagonal block in ONE launch, issued with the first step: the workgroup keeps its CU (potrf.hip)
+      if (k == 0) GPX_RET(launch_potrf_chain(h, P, (int)nb, A, ld, L, ld, h->d_W, h->d_info, (int)nblk, flagsU, n_signal, flagsW));
+    } else {
+      prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
+      GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
+                                h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr,
+                                (resident && k >= 1) ? flagsU + (k - 1) : nullptr, n_signal,
+                                (chain2 && need_w && k + 1 < nblk) ? flagsW + k : nullptr));
+      prof_end(h, P);
+    }
     if (!need_w) return GPX_OK;
     if (k + 1 >= nblk && !kinv) {
       // the last panel is the border rows only and nothing follows it but the epilogue: it runs on the chain stream,
@@ -896,7 +905,7 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
       prof_end(h, P);
       return GPX_OK;   // (the gradient path keeps its last panel on Q: the K^-1 update behind it belongs to T's sequence)
     }
-    if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
+    if (!attach && !persist) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
     w_rec[(size_t)k].store(1, std::memory_order_release);
     if (k + 1 >= nblk) return GPX_OK;
     if (k >= 1) {   // columns k, k+1 were brought up to date by Q at step k-1
@@ -985,7 +994,8 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
     if (!await(w_rec[(size_t)k])) return GPX_ERR_HIP;
     // (Starting the panel kernel resident too -- it would sleep on potrf_diag's flag instead of waiting ~8 us for the
     // cross-stream event -- crowds the bulk update with sleeping workgroups: 1.76 -> 1.81 ms, not used.)
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
+    if (persist) GPX_RET(launch_flag_relay(h, Q, flagsW + k, 1u, h->d_info));   // W_k: the one potrf_diag launch raises flagsW[k]
+    else GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
     {
       GemmLaunch g;
       g.A = A + r0 * ld + c0; g.lda = ld;

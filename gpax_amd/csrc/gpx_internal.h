@@ -96,6 +96,11 @@ struct GemmLaunch {
   int* wait_info = nullptr;   // device int set to -7 if the bounded wait gives up
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
+// every diagonal block of a factorisation in ONE launch (block k waits for flagsU[k-1] >= n_signal, raises flagsW[k]) and the
+// one-wave relay that lets a stream wait for such a flag
+int launch_potrf_chain(gpx_handle* h, hipStream_t s, int nb, const double* A0, int64_t lda, double* L0, int64_t ldl, double* W0,
+                       int* info, int nblk, const unsigned* flagsU, unsigned n_signal, unsigned* flagsW);
+int launch_flag_relay(gpx_handle* h, hipStream_t s, const unsigned* flag, unsigned count, int* info);
 // the chain's two band kernels in one launch; Z (optional): an update of the same diagonal block applied first, before the wait for W_k
 int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch* Z, const GemmLaunch& S, const GemmLaunch& U);
 
@@ -218,6 +223,7 @@ struct gpx_handle {
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 28;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 40;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int potrf_persist = 0;   // in-kernel hand-over schedule: ONE potrf_diag launch for all diagonal blocks (keeps its CU), relay kernels hand W_k to the panel stream.  Measured SLOWER (N=1024 +4 %, 4096 +1.6 %, 16384 +4 %): off
   int epi_split = 1;   // fit+predict: the posterior / log-marginal reductions over all block columns but the last run on the panel stream beside the last potrf_diag
   int lp_flag = 1;     // the last border panel waits for the panel stream's last column update through a device counter (0: a stream-level event wait in front of the last potrf_diag)
   int diag_band = 1;   // fused band kernel, ungrouped steps: panel k-1's update of block (k+1,k+1) is done by the band kernel of step k while it waits for potrf_diag(k)

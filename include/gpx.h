@@ -184,6 +184,8 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  columns remain; 0 = never (28 / 40)
  *   "diag_band"    fused band kernel, ungrouped steps: the previous panel's update of the diagonal block is done by the band kernel
  *                  itself while it waits for potrf_diag; the panel stream's update of column k+2 starts below that block (1)
+ *   "potrf_persist" ONE potrf_diag launch for all diagonal blocks of a factorisation (the workgroup keeps its CU; one-wave relay
+ *                  kernels hand W_k to the panel stream).  Measured slower than one launch per block (0)
  *   "epi_split"    fit+predict: the posterior / log-marginal reductions over all block columns but the last are taken on the
  *                  panel stream as soon as those columns are final (beside the last potrf_diag); the epilogue behind the last
  *                  panel only adds the last block column (1)

@@ -236,6 +236,8 @@ def test_schedule_switches_are_bit_identical(core, off, n, m, grouped):
         ref = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
         for name in off:
             core.set_option(name, 0)
+        if off == ("near_block",):
+            core.set_option("potrf_persist", 1)   # and the one-launch potrf_diag chain (off by default) rides along here
         for _ in range(3):
             got = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
             assert got[0] == ref[0] == 0 and got[1] == ref[1]
@@ -243,6 +245,7 @@ def test_schedule_switches_are_bit_identical(core, off, n, m, grouped):
     finally:
         for name in ("fuse_band", "diag_band", "lp_flag", "border_side", "near_block"):
             core.set_option(name, 1)
+        core.set_option("potrf_persist", 0)
         core.set_option("resident", 2)
         core.set_option("nb", 0)
         core.set_option("pair_min", 28)
