@@ -451,6 +451,10 @@ __global__ __launch_bounds__(256, GEMM_PERSIST_WAVES) void gemm_nt_persist_kerne
 // written and measured: 41.9 vs 46.1 TFLOP/s at M=4736 N=3712 K=128, 1.91 vs 1.76 ms per N = 4096 step.  Like the
 // tile-pipelined kernel below and the 128x128 tiles, it loses to plain one-tile workgroups: the hardware dispatcher
 // de-correlates the phases of the three workgroups of a CU, resident workgroups stay in lock-step.  Removed.)
+// (A K = 128 specialisation with every global load of the tile in flight at once -- both K-halves and the C tile requested up
+// front, the halves through a 69.6 KB LDS image one after the other, three barriers per tile instead of eight, two
+// workgroups per CU -- was written and measured: 40.5 vs 46.2 TFLOP/s at M=4736 N=3712, 1.67 vs 1.62 ms per N = 4096 step.
+// Fifth variant to lose to three 4-wave workgroups per CU on the chunked pipeline.  Removed.)
 // (A 128x128-tile kernel -- 64x64 per wave, 128 accumulator VGPRs, accumulators initialised from C, K in chunks of 16
 // through a double-buffered LDS image, two workgroups per CU -- halves the operand bytes per flop but measured slower
 // than the 64x64 kernel at every shape: 38 vs 44 TFLOP/s at M=4736 N=3712 K=128, 60.5 vs 65.9 at 24576^2 K=512.  With
