@@ -315,6 +315,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_LP_FLAG"))) h->lp_flag = atoi(env) != 0;
   if ((env = getenv("GPX_EPI_SPLIT"))) h->epi_split = atoi(env) != 0;
   if ((env = getenv("GPX_POTRF_PERSIST"))) h->potrf_persist = atoi(env) != 0;
+  if ((env = getenv("GPX_BUILD_SMALL"))) h->build_small = atoi(env) != 0;
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -397,6 +398,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "lp_flag")) { h->lp_flag = value != 0; return GPX_OK; }
   if (!strcmp(name, "epi_split")) { h->epi_split = value != 0; return GPX_OK; }
   if (!strcmp(name, "potrf_persist")) { h->potrf_persist = value != 0; return GPX_OK; }
+  if (!strcmp(name, "build_small")) { h->build_small = value != 0; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -420,6 +422,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "lp_flag")) { *value = h->lp_flag; return GPX_OK; }
   if (!strcmp(name, "epi_split")) { *value = h->epi_split; return GPX_OK; }
   if (!strcmp(name, "potrf_persist")) { *value = h->potrf_persist; return GPX_OK; }
+  if (!strcmp(name, "build_small")) { *value = h->build_small; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -1261,6 +1264,18 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     return rc;
   };
   double fl, by;
+  if (h->build_small && npad == h->nb && !fp.want_k && !K_out) {
+    // one block column: the whole bordered matrix in ONE launch (gram.hip) -- at these sizes the step is launch latency
+    gram_cost(0, n, &fl, &by);
+    prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
+    GPX_RET(launch_build_small(h, s, fp.kind, h->d_x, h->d_xnew, h->d_hyp, dev_scalars, fp.noise_dev, h->d_r, h->d_A, ld, n, npad,
+                               m_rows, fp.with_r ? npad + m_rows : -1, rows, d, fp.apply_noise ? 1 : 0, h->d_info, nullptr, 0));
+    prof_end(h, s);
+    const int lrc = factor_loop(h, rows);
+    h->flags_clean = false;
+    GPX_RET(lrc);
+    return GPX_OK;
+  }
   g.zero_info = h->d_info;
   if (h->d_flags) {   // the hand-over flags of the split-panel schedule are cleared by the same launch
     g.zero_flags = h->d_flags; g.n_zero_flags = (int)(3 * (npad / h->nb));
@@ -1468,11 +1483,21 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   h->have_r = true;
 
   // ---- [K ; r ; I] in d_A
+  const bool one_launch = h->build_small && npad == nb;   // one block column: one launch builds everything below (gram.hip)
+  if (one_launch) {
+    const double T = (double)((n + 63) / 64);
+    const double entries = T * (T + 1) / 2.0 * 4096.0;
+    prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(p->kind, d) * entries, 8.0 * entries + 16.0 * n * d);
+    GPX_RET(launch_build_small(h, s, p->kind, h->d_x, nullptr, h->d_hyp, h->d_hyp + 2 * d, noise_dev, h->d_r, h->d_A, ld, n, npad, 0,
+                               npad, rows, d, p->apply_noise ? 1 : 0, h->d_info, nullptr, 0, npad + RZ, h->d_L + npad * ld));
+    prof_end(h, s);
+  }
   GramLaunch g;
   g.kind = p->kind; g.d = d; g.k_scale = 0.0; g.hyp = h->d_hyp; g.dev_scalars = h->d_hyp + 2 * d;
   g.x1 = h->d_x; g.x2 = h->d_x; g.n1 = n; g.n2 = n; g.out = h->d_A; g.ld = ld;
   g.lower_only = 1; g.diag_rule = p->apply_noise ? 1 : 0;
   g.noise = noise_dev; g.noise_scalar = 0.0; g.jitter = 0.0;
+  if (!one_launch) {
   {
     const double T = (double)((n + 63) / 64);
     const double entries = T * (T + 1) / 2.0 * 4096.0;
@@ -1489,6 +1514,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   // border rows of L that no panel writes (the dead lower-left of U) must read as zeros
   GPX_HIP_CHECK(h, hipMemsetAsync(h->d_L + npad * ld, 0, (size_t)(epad * ld) * sizeof(double), s));
   GPX_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
+  }
 
   const double* zrow = h->d_L + npad * ld;
   const double* U = h->d_L + (npad + RZ) * ld;

@@ -67,6 +67,11 @@ struct GramLaunch {
   hipEvent_t start_event = nullptr, stop_event = nullptr;   // the kernel's own dispatch timestamps (profiling)
 };
 int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& g);
+// one-block-column problems: [K ; identity padding ; k_cross ; r ; zero rows] in ONE launch (same bits as the separate launches)
+int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* xnew, const double* hyp,
+                       const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
+                       int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
+                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0 = -1, double* zero2 = nullptr);
 
 // C[M,N] = beta*C + alpha * A[M,K] * B[N,K]^T   (all row-major; K contiguous in A and B)
 struct GemmLaunch {
@@ -223,6 +228,7 @@ struct gpx_handle {
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 28;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 40;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int build_small = 1;     // one block column: the whole bordered matrix is built by one launch
   int potrf_persist = 0;   // in-kernel hand-over schedule: ONE potrf_diag launch for all diagonal blocks (keeps its CU), relay kernels hand W_k to the panel stream.  Measured SLOWER (N=1024 +4 %, 4096 +1.6 %, 16384 +4 %): off
   int epi_split = 1;   // fit+predict: the posterior / log-marginal reductions over all block columns but the last run on the panel stream beside the last potrf_diag
   int lp_flag = 1;     // the last border panel waits for the panel stream's last column update through a device counter (0: a stream-level event wait in front of the last potrf_diag)

@@ -175,6 +175,84 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   return GPX_OK;
 }
 
+// ---- one launch for the whole bordered matrix of a ONE-block-column problem (n <= nb) -------------------------
+// [K ; identity padding ; k_cross ; r ; zero rows], npad columns: what gram + 2 fills + cross gram + border rows build
+// in five launches.  At these sizes (the reference's own examples: 25-256 points) a step is bound by launch latency,
+// ~8-10 us per kernel in a stream, not by arithmetic.  One thread per entry, inputs straight from L2; the same
+// arithmetic in the same order as gram_kernel (scaled coordinates, differences, fma accumulation, same epilogues), so
+// the entries carry the same bits.
+struct BuildArgs {
+  const double* x; const double* xnew; const double* hyp; const double* dev_scalars; const double* noise; const double* r;
+  double* out; int64_t ld;
+  int64_t n, npad, m_rows, r_row, rows_total;
+  int d, diag_rule;
+  int* zero_info; unsigned* zero_flags; int n_zero_flags;
+  int64_t ident_row0;   // >= 0: rows [ident_row0, ident_row0 + n) are identity rows (the gradient path's border: they become U = L^-T)
+  double* zero2;        // when set: a second matrix (same ld) whose rows >= npad are cleared by the same launch (the border of L)
+};
+
+template <int KIND>
+__global__ void build_small_kernel(BuildArgs g) {
+  const int64_t row = blockIdx.x, col = threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (g.zero_info && threadIdx.x == 0) *g.zero_info = 0;
+    if (g.zero_flags) for (int i = threadIdx.x; i < g.n_zero_flags; i += blockDim.x) g.zero_flags[i] = 0u;
+  }
+  if (col >= g.npad) return;
+  double* dst = g.out + row * g.ld + col;
+  if (g.zero2 && row >= g.npad) g.zero2[(row - g.npad) * g.ld + col] = 0.0;
+  const double* x1 = nullptr;
+  bool diag_row = false;
+  if (row < g.n) { x1 = g.x + row * g.d; diag_row = g.diag_rule != 0; }
+  else if (row < g.npad) { *dst = (row == col) ? 1.0 : 0.0; return; }
+  else if (row < g.npad + g.m_rows) x1 = g.xnew + (row - g.npad) * g.d;
+  else if (row == g.r_row) { *dst = (col < g.n && g.r) ? g.r[col] : 0.0; return; }
+  else if (g.ident_row0 >= 0 && row >= g.ident_row0 && row < g.ident_row0 + g.n) { *dst = (col == row - g.ident_row0) ? 1.0 : 0.0; return; }
+  else { *dst = 0.0; return; }
+  if (col >= g.n) { *dst = 0.0; return; }
+  const double* x2 = g.x + col * g.d;
+  double acc = 0.0;
+  for (int k = 0; k < g.d; ++k) {
+    const double len = g.hyp[k];
+    double a = x1[k], b = x2[k];
+    if (KIND != GPX_PERIODIC) { a = a / len; b = b / len; }
+    double d0 = a - b;
+    if (KIND == GPX_PERIODIC) d0 = sin(M_PI * d0 / g.hyp[g.d + k]) / len;
+    acc = fma(d0, d0, acc);
+  }
+  const double k_scale = g.dev_scalars[0], noise_scalar = g.dev_scalars[1], jitter = g.dev_scalars[2];
+  double kv;
+  if (KIND == GPX_RBF) kv = k_scale * exp(-0.5 * acc);
+  else if (KIND == GPX_MATERN52) {
+    const double rr = sqrt(acc + 1e-12);
+    const double s5r = 2.2360679774997896964 * rr;
+    kv = k_scale * (1.0 + s5r + (5.0 / 3.0) * acc) * exp(-s5r);
+  } else kv = k_scale * exp(-2.0 * acc);
+  if (diag_row && row == col) kv += ((g.noise ? g.noise[row] : noise_scalar) + jitter);
+  *dst = kv;
+}
+
+int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* xnew, const double* hyp,
+                       const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
+                       int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
+                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0, double* zero2) {
+  if (npad > 128 || npad <= 0 || !dev_scalars) { gpx_set_error(h, "build_small: one block column only"); return GPX_ERR_ARG; }
+  BuildArgs g;
+  g.x = x; g.xnew = xnew; g.hyp = hyp; g.dev_scalars = dev_scalars; g.noise = noise; g.r = r; g.out = out; g.ld = ld;
+  g.n = n; g.npad = npad; g.m_rows = m_rows; g.r_row = r_row; g.rows_total = rows_total; g.d = d; g.diag_rule = diag_rule;
+  g.zero_info = zero_info; g.zero_flags = zero_flags; g.n_zero_flags = n_zero_flags;
+  g.ident_row0 = ident_row0; g.zero2 = zero2;
+  const dim3 grid((unsigned)rows_total), block((unsigned)(npad <= 64 ? 64 : 128));
+  switch (kind) {
+    case GPX_RBF: hipLaunchKernelGGL((build_small_kernel<GPX_RBF>), grid, block, 0, s, g); break;
+    case GPX_MATERN52: hipLaunchKernelGGL((build_small_kernel<GPX_MATERN52>), grid, block, 0, s, g); break;
+    case GPX_PERIODIC: hipLaunchKernelGGL((build_small_kernel<GPX_PERIODIC>), grid, block, 0, s, g); break;
+    default: gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
+  }
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
 // ------------------------------------------------------------------- fill helpers
 
 // out[r][c] = (r == c) ? diag : 0   for r in [r0,r1), c in [c0,c1)

@@ -184,6 +184,8 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  columns remain; 0 = never (28 / 40)
  *   "diag_band"    fused band kernel, ungrouped steps: the previous panel's update of the diagonal block is done by the band kernel
  *                  itself while it waits for potrf_diag; the panel stream's update of column k+2 starts below that block (1)
+ *   "build_small"  one block column (n <= nb): the whole bordered matrix -- K, identity padding, k_cross, r, identity / zero
+ *                  border rows, the cleared border of L -- is built by ONE launch instead of five to nine (1)
  *   "potrf_persist" ONE potrf_diag launch for all diagonal blocks of a factorisation (the workgroup keeps its CU; one-wave relay
  *                  kernels hand W_k to the panel stream).  Measured slower than one launch per block (0)
  *   "epi_split"    fit+predict: the posterior / log-marginal reductions over all block columns but the last are taken on the
