@@ -1530,11 +1530,10 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   e.L = h->d_L; e.ld = ld; e.n = n; e.z = zrow; e.vt = nullptr; e.vt_ld = 0; e.m = 0; e.m_new = nullptr;
   e.prior_diag = 0.0; e.scal = h->d_scal; e.mean = nullptr; e.var = nullptr;
   e.z_copy = h->d_z; e.npad = npad;
-  GPX_RET(launch_epilogue(h, s, e));
-
-  // ---- alpha = L^-T z = U z
+  // ---- alpha = L^-T z = U z rides on the epilogue's launch (extra blocks; it reads z from the border row itself)
   double* alpha = h->d_mean;   // inside the result block
-  GPX_RET(launch_utri_gemv(h, s, U, ld, h->d_z, alpha, n, npad));
+  e.gemv_U = U; e.gemv_alpha = alpha; e.gemv_ncols = npad;
+  GPX_RET(launch_epilogue(h, s, e));
 
   // ---- K^-1 = U U^T, lower 64x64 tiles; U_ik = 0 for k < i, so each tile starts at its first row
   if (!fused_kinv) {

@@ -142,6 +142,8 @@ struct EpilogueLaunch {
   double* scal;                  // device: [0]=logdet [1]=quad
   double* mean; double* var;     // device (m)
   double* z_copy = nullptr; int64_t npad = 0;   // also copy z[0:npad) here (the handle's z for later posterior calls)
+  // gradient path: alpha = U z (U = L^-T, ld as L, rows n, columns gemv_ncols) computed by extra blocks of the same launch
+  const double* gemv_U = nullptr; double* gemv_alpha = nullptr; int64_t gemv_ncols = 0;
 };
 int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
 // split epilogue: columns [0, c1) early as partial sums (part: 2 + 2 m doubles), then [c1, n) + part, finalised

@@ -60,7 +60,20 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
                                                       double* z_copy, int64_t npad, double* scal, const double* vt,
                                                       int64_t vt_ld, const double* m_new, double prior_diag,
                                                       const double* dev_prior_diag, double* mean, double* var,
-                                                      int64_t c0, int64_t c1, double* part, int64_t m, int mode) {
+                                                      int64_t c0, int64_t c1, double* part, int64_t m, int mode,
+                                                      const double* U, double* alpha, int64_t gemv_ncols, int gemv_block0) {
+  if (U && (int)blockIdx.x >= gemv_block0) {
+    // gradient path, riding on the same launch: alpha_i = sum_{k >= i} U_ik z_k (U = L^-T, row-major), one wave per row
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)(blockIdx.x - gemv_block0) * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double* u = U + row * ld;
+    double s = 0.0;
+    for (int64_t k = row + lane; k < gemv_ncols; k += 64) s = fma(u[k], z[k], s);
+    s = wave_sum(s);
+    if (lane == 0) alpha[row] = s;
+    return;
+  }
   if (blockIdx.x == 0) {
     double s1 = 0.0, s2 = 0.0;
     if (mode != 1 && z_copy)
@@ -97,9 +110,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
 
 static int launch_epilogue_range(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c0, int64_t c1, double* part, int mode) {
   const int64_t rows = (e.m > 0 && e.z) ? e.m : 0;
-  hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(rows + 1)), dim3(256), 0, s, e.L, e.ld, e.n, e.z, e.z_copy,
+  const int64_t gemv_blocks = (e.gemv_U && e.z) ? (e.n + 3) / 4 : 0;
+  hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(rows + 1 + gemv_blocks)), dim3(256), 0, s, e.L, e.ld, e.n, e.z, e.z_copy,
                      e.z_copy ? e.npad : e.n, e.scal, e.vt, e.vt_ld, e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var,
-                     c0, c1, part, rows, mode);
+                     c0, c1, part, rows, mode, gemv_blocks ? e.gemv_U : nullptr, e.gemv_alpha, e.gemv_ncols, (int)(rows + 1));
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
