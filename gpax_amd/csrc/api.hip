@@ -316,6 +316,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   if ((env = getenv("GPX_EPI_SPLIT"))) h->epi_split = atoi(env) != 0;
   if ((env = getenv("GPX_POTRF_PERSIST"))) h->potrf_persist = atoi(env) != 0;
   if ((env = getenv("GPX_BUILD_SMALL"))) h->build_small = atoi(env) != 0;
+  if ((env = getenv("GPX_SPLIT_MIN_BLOCKS"))) h->split_min_blocks = std::max(atoi(env), 2);
   if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
@@ -399,6 +400,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "epi_split")) { h->epi_split = value != 0; return GPX_OK; }
   if (!strcmp(name, "potrf_persist")) { h->potrf_persist = value != 0; return GPX_OK; }
   if (!strcmp(name, "build_small")) { h->build_small = value != 0; return GPX_OK; }
+  if (!strcmp(name, "split_min_blocks")) { h->split_min_blocks = (int)std::max<int64_t>(value, 2); return GPX_OK; }
   if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
   if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -423,6 +425,7 @@ extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!strcmp(name, "epi_split")) { *value = h->epi_split; return GPX_OK; }
   if (!strcmp(name, "potrf_persist")) { *value = h->potrf_persist; return GPX_OK; }
   if (!strcmp(name, "build_small")) { *value = h->build_small; return GPX_OK; }
+  if (!strcmp(name, "split_min_blocks")) { *value = h->split_min_blocks; return GPX_OK; }
   if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
   if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
   gpx_set_error(h, std::string("unknown option ") + name);
@@ -645,10 +648,11 @@ static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base
 static int factor_loop(gpx_handle* h, int64_t rows_total, int64_t tri_base = -1) {
   // one block column (n <= nb): potrf_diag and the border rows' panel solve, nothing to overlap -- one stream,
   // no events (the multi-stream machinery costs ~20 us of hand-overs on a ~60 us step)
-  if (h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= 2) return factor_loop_split(h, rows_total, tri_base);
+  // two block columns: one stream as well (measured: 0.136 -> 0.115 ms per N = 256 step; from three on the split schedule wins)
+  if (h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= h->split_min_blocks) return factor_loop_split(h, rows_total, tri_base);
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld;
   const int64_t nblk = npad / nb;
-  const bool la = h->lookahead != 0 && nblk >= 2;
+  const bool la = h->lookahead != 0 && nblk >= (h->depth >= 3 ? h->split_min_blocks : 2);
   const int D = la ? (h->depth >= 2 ? 2 : 1) : 1;
   hipStream_t P = h->s_main, T = la ? h->s_trail : h->s_main, Q = (la && D >= 2) ? h->s_far : h->s_main;
   double* A = h->d_A; double* L = h->d_L;
@@ -1264,7 +1268,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     return rc;
   };
   double fl, by;
-  if (h->build_small && npad == h->nb && !fp.want_k && !K_out) {
+  if (h->build_small && npad <= 256 && npad / h->nb < h->split_min_blocks && !fp.want_k && !K_out) {
     // one block column: the whole bordered matrix in ONE launch (gram.hip) -- at these sizes the step is launch latency
     gram_cost(0, n, &fl, &by);
     prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
@@ -1294,7 +1298,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   // first reader, while the chain stream goes straight from K to potrf_diag(0) -- ~30 us off the head of the step.
   // (Building most of K itself on the bulk stream while the chain already factorises was tried: no gain at N = 4096,
   // 1.907 vs 1.905 ms -- the first steps are bound by that stream.)
-  const bool border_on_q = h->border_side && h->lookahead != 0 && h->depth >= 3 && npad / h->nb >= 2 && !h->in_capture && h->prof_mode != 1;
+  const bool border_on_q = h->border_side && h->lookahead != 0 && h->depth >= 3 && npad / h->nb >= h->split_min_blocks && !h->in_capture && h->prof_mode != 1;
   hipStream_t sb = s;
   if (border_on_q) {
     sb = h->s_far;
@@ -1483,7 +1487,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   h->have_r = true;
 
   // ---- [K ; r ; I] in d_A
-  const bool one_launch = h->build_small && npad == nb;   // one block column: one launch builds everything below (gram.hip)
+  const bool one_launch = h->build_small && npad <= 256 && npad / nb < h->split_min_blocks;   // one stream, small: one launch builds everything below (gram.hip)
   if (one_launch) {
     const double T = (double)((n + 63) / 64);
     const double entries = T * (T + 1) / 2.0 * 4096.0;
@@ -1520,7 +1524,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   const double* U = h->d_L + (npad + RZ) * ld;
   // K^-1 = U U^T (lower 64x64 tiles) is accumulated panel by panel inside the split-panel schedule; the classic
   // schedules (options "depth" 1|2, "lookahead" 0) form it in one product after the factorisation
-  const bool fused_kinv = h->lookahead != 0 && h->depth >= 3 && npad / nb >= 2;   // same test as factor_loop's dispatch
+  const bool fused_kinv = h->lookahead != 0 && h->depth >= 3 && npad / nb >= h->split_min_blocks;   // same test as factor_loop's dispatch
   if (fused_kinv) { h->kinv_U = U; h->kinv_rows = n64; }
   int frc = factor_loop(h, rows, npad + RZ);
   h->kinv_U = nullptr; h->kinv_rows = 0;
@@ -1753,7 +1757,7 @@ static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
   e.z_copy = h->d_z; e.npad = h->npad;   // keep z for later posterior calls against the cached factor
   // split epilogue (split-panel schedule, three block columns or more): see side() in factor_loop_split
   h->epi = nullptr; h->epi_split_col = 0;
-  if (h->epi_split && !h->in_capture && h->prof_mode != 1 && h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= 3) {
+  if (h->epi_split && !h->in_capture && h->prof_mode != 1 && h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= std::max(3, h->split_min_blocks)) {
     GPX_RET(ensure(h, &h->d_epart, &h->epart_cap, 2 + 2 * std::max<int64_t>(m, 1)));
     h->epi = &e;
   }

@@ -230,6 +230,7 @@ struct gpx_handle {
   int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
   int pair_min = 28;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 40;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int split_min_blocks = 3;   // the split-panel (multi-stream) schedule runs from this many block columns; below, one stream
   int build_small = 1;     // one block column: the whole bordered matrix is built by one launch
   int potrf_persist = 0;   // in-kernel hand-over schedule: ONE potrf_diag launch for all diagonal blocks (keeps its CU), relay kernels hand W_k to the panel stream.  Measured SLOWER (N=1024 +4 %, 4096 +1.6 %, 16384 +4 %): off
   int epi_split = 1;   // fit+predict: the posterior / log-marginal reductions over all block columns but the last run on the panel stream beside the last potrf_diag

@@ -175,7 +175,7 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   return GPX_OK;
 }
 
-// ---- one launch for the whole bordered matrix of a ONE-block-column problem (n <= nb) -------------------------
+// ---- one launch for the whole bordered matrix of a one- or two-block-column problem (npad <= 256) -------------
 // [K ; identity padding ; k_cross ; r ; zero rows], npad columns: what gram + 2 fills + cross gram + border rows build
 // in five launches.  At these sizes (the reference's own examples: 25-256 points) a step is bound by launch latency,
 // ~8-10 us per kernel in a stream, not by arithmetic.  One thread per entry, inputs straight from L2; the same
@@ -236,13 +236,13 @@ int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, 
                        const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
                        int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
                        unsigned* zero_flags, int n_zero_flags, int64_t ident_row0, double* zero2) {
-  if (npad > 128 || npad <= 0 || !dev_scalars) { gpx_set_error(h, "build_small: one block column only"); return GPX_ERR_ARG; }
+  if (npad > 256 || npad <= 0 || !dev_scalars) { gpx_set_error(h, "build_small: at most 256 columns"); return GPX_ERR_ARG; }
   BuildArgs g;
   g.x = x; g.xnew = xnew; g.hyp = hyp; g.dev_scalars = dev_scalars; g.noise = noise; g.r = r; g.out = out; g.ld = ld;
   g.n = n; g.npad = npad; g.m_rows = m_rows; g.r_row = r_row; g.rows_total = rows_total; g.d = d; g.diag_rule = diag_rule;
   g.zero_info = zero_info; g.zero_flags = zero_flags; g.n_zero_flags = n_zero_flags;
   g.ident_row0 = ident_row0; g.zero2 = zero2;
-  const dim3 grid((unsigned)rows_total), block((unsigned)(npad <= 64 ? 64 : 128));
+  const dim3 grid((unsigned)rows_total), block((unsigned)(npad <= 64 ? 64 : (npad <= 128 ? 128 : 256)));
   switch (kind) {
     case GPX_RBF: hipLaunchKernelGGL((build_small_kernel<GPX_RBF>), grid, block, 0, s, g); break;
     case GPX_MATERN52: hipLaunchKernelGGL((build_small_kernel<GPX_MATERN52>), grid, block, 0, s, g); break;

@@ -184,7 +184,8 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  columns remain; 0 = never (28 / 40)
  *   "diag_band"    fused band kernel, ungrouped steps: the previous panel's update of the diagonal block is done by the band kernel
  *                  itself while it waits for potrf_diag; the panel stream's update of column k+2 starts below that block (1)
- *   "build_small"  one block column (n <= nb): the whole bordered matrix -- K, identity padding, k_cross, r, identity / zero
+ *   "split_min_blocks" the split-panel (three-stream) schedule runs from this many block columns; below, one stream (3)
+ *   "build_small"  one or two block columns on one stream (npad <= 256): the whole bordered matrix -- K, identity padding, k_cross, r, identity / zero
  *                  border rows, the cleared border of L -- is built by ONE launch instead of five to nine (1)
  *   "potrf_persist" ONE potrf_diag launch for all diagonal blocks of a factorisation (the workgroup keeps its CU; one-wave relay
  *                  kernels hand W_k to the panel stream).  Measured slower than one launch per block (0)

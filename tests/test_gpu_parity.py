@@ -230,6 +230,7 @@ def test_schedule_switches_are_bit_identical(core, off, n, m, grouped):
         core.set_option("nb", 64)
         core.set_option("pair_min", 6)
         core.set_option("quad_min", 12)
+    core.set_option("split_min_blocks", 2)   # two block columns run on one stream by default: keep the split machinery covered there
     core.set_train(x)
     core.set_test(xn)
     try:
@@ -246,6 +247,7 @@ def test_schedule_switches_are_bit_identical(core, off, n, m, grouped):
         for name in ("fuse_band", "diag_band", "lp_flag", "border_side", "near_block"):
             core.set_option(name, 1)
         core.set_option("potrf_persist", 0)
+        core.set_option("split_min_blocks", 3)
         core.set_option("resident", 2)
         core.set_option("nb", 0)
         core.set_option("pair_min", 28)

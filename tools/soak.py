@@ -15,6 +15,7 @@ total = 0
 # with the panel stream's last column update
 for n, m, reps in ((200, 250, 3000), (256, 1000, 2000), (300, 17, 400), (700, 50, 400), (1500, 100, 300), (2500, 333, 200), (4096, 1000, 300), (6000, 10, 50)):
     d = 5
+    c.set_option("split_min_blocks", 2 if n <= 256 else 3)   # two block columns run on one stream by default: soak the split path there too
     x = rng.uniform(-1, 1, (n, d)); xn = rng.uniform(-1, 1, (m, d)); y = rng.standard_normal(n)
     c.set_train(x); c.set_test(xn); c.set_targets(y, np.ones(m))
     p = gpax_amd.make_params(1, 1.3, rng.uniform(0.5, 1.5, d), None, np.array([0.01]), 1e-6)
