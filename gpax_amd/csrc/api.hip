@@ -1555,7 +1555,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
 
   // ---- the reduction
   const int64_t T = (n + 63) / 64, ntiles = T * (T + 1) / 2;
-  const int nwg = (int)std::min<int64_t>(ntiles, 1024);
+  const int nwg = ntiles <= 3 ? 1 : (int)std::min<int64_t>(ntiles, 1024);   // up to three tiles (n <= 128): one workgroup, no final-sum launch
   GPX_RET(ensure(h, &h->d_gpart, &h->gpart_cap, (int64_t)nchunk * nwg * NPVv));
   double* sums_dev = h->d_mean + npad;
   GPX_RET(launch_grad_reduce(h, s, p->kind, h->d_x, h->d_hyp, h->d_kinv, npad, alpha, n, d, per_dim, nwg, h->d_gpart,

@@ -237,6 +237,10 @@ int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, 
     gpx_set_error(h, "grad_reduce: K^-1 buffer must be 16-B aligned with an even leading dimension");
     return GPX_ERR_ARG;
   }
+  // one workgroup per chunk: its partial sums ARE the sums (same layout), no final-sum launch -- at the sizes where this
+  // applies (the caller passes nwg = 1 for up to three tiles) a launch costs more than the three tiles
+  const bool direct = nwg == 1;
+  if (direct) g.part = sums;
   dim3 grid((unsigned)nwg, (unsigned)nchunk);
   switch (kind) {
     case GPX_RBF: hipLaunchKernelGGL((grad_reduce_kernel<GPX_RBF>), grid, dim3(256), 0, s, g); break;
@@ -245,6 +249,7 @@ int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, 
     default: gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
   }
   GPX_HIP_CHECK(h, hipGetLastError());
+  if (direct) return GPX_OK;
   hipLaunchKernelGGL(grad_final_kernel, dim3(NPV, (unsigned)nchunk), dim3(256), 0, s, part, sums, nwg);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
