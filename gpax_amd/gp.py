@@ -25,11 +25,15 @@ import numpy as np
 
 from gpax_amd import _lib, mcmc, state
 from gpax_amd.kernels import Kernel
+from gpax_amd.utils.prior_utils import Distribution as _Distribution
 from gpax_amd.means import ConstantMean, Mean
 from gpax_amd.transforms import IdentityTransform, NormalizeTransform, ScaleTransform, Transform
 
 DATA_TYPES = (np.ndarray, type(None))
 Y_STD_DATA_TYPES = DATA_TYPES + (float, int)
+
+
+_PositiveBijection = _Distribution.from_unconstrained   # the default exp bijection (fast_terms assumes it)
 
 
 class GPSample:
@@ -447,10 +451,16 @@ class _ParamSpace:
         with np.errstate(all="ignore"):   # far-out trial points of the step-size search overflow to a rejected -inf
             for name, dist, plate in self.items:
                 uu = u[o : o + plate]
-                x, dxdu, gterm = dist.grad_terms(uu)
-                _, lj = dist.from_unconstrained(uu)
-                params[name] = np.asarray(x, dtype=np.float64)
-                log_prior += float(np.asarray(dist.log_prob(x)).sum() + np.asarray(lj).sum())
+                fast = getattr(dist, "fast_terms", None)
+                if fast is not None and type(dist).from_unconstrained is _PositiveBijection:   # exp bijection, closed forms
+                    x, dxdu, gterm, lp = fast(np.asarray(uu, dtype=np.float64))
+                    params[name] = x
+                    log_prior += lp
+                else:
+                    x, dxdu, gterm = dist.grad_terms(uu)
+                    _, lj = dist.from_unconstrained(uu)
+                    params[name] = np.asarray(x, dtype=np.float64)
+                    log_prior += float(np.asarray(dist.log_prob(x)).sum() + np.asarray(lj).sum())
                 dx[o : o + plate], g_prior[o : o + plate] = dxdu, gterm
                 o += plate
         if not math.isfinite(log_prior):

@@ -77,6 +77,14 @@ class HalfNormal(Distribution):
     def grad_log_prob(self, x):
         return -np.asarray(x, dtype=np.float64) / self.scale**2
 
+    def fast_terms(self, u):
+        """``grad_terms`` + log-density in one pass for the exp bijection: ``(x, dx/du, d/du[...], sum(log_prob(x) + u))``
+        with one ``exp`` -- what a NUTS gradient call needs per parameter (the general path costs ~15 us per parameter)."""
+        x = np.exp(u)
+        q = (x / self.scale) ** 2
+        lp = u.size * (0.5 * math.log(2 / math.pi) - math.log(self.scale)) + float(u.sum() - 0.5 * q.sum())
+        return x, x, 1.0 - q, lp
+
     @property
     def median(self):
         return self.scale * math.sqrt(2.0) * float(erfinv(0.5))
@@ -105,6 +113,13 @@ class LogNormal(Distribution):
     def grad_log_prob(self, x):
         x = np.asarray(x, dtype=np.float64)
         return -(1.0 + (np.log(x) - self.loc) / self.scale**2) / x
+
+    def fast_terms(self, u):
+        """See ``HalfNormal.fast_terms``: with x = exp(u), log_prob(x) + u = -log(scale) - log(2 pi)/2 - z^2/2, z = (u - loc)/scale."""
+        x = np.exp(u)
+        z = (u - self.loc) / self.scale
+        lp = -u.size * (math.log(self.scale) + 0.5 * math.log(2 * math.pi)) - 0.5 * float((z * z).sum())
+        return x, x, -z / self.scale, lp
 
     @property
     def median(self):
