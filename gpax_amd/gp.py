@@ -134,14 +134,25 @@ class GaussianProcess:
     def _class_specific_post_init(self):
         pass
 
+    def _memo(self, name, key, make):
+        """Per-instance cache of a derived array, keyed by the identity of what it is derived from (x, y and the
+        transforms are fixed after construction, as in the reference; replacing the attribute invalidates the entry)."""
+        memo = self.__dict__.setdefault("_memo_store", {})
+        hit = memo.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, make())
+            memo[name] = hit
+        return hit[1]
+
     @property
     def x_transformed(self):
-        return self.input_transform.forward(self.x, transforms_as="mean")
+        return self._memo("x", (id(self.x), id(self.input_transform)),
+                          lambda: self.input_transform.forward(self.x, transforms_as="mean"))
 
     @property
     def y_transformed(self):
-        y = self.output_transform.forward(self.y, transforms_as="mean")
-        return np.atleast_1d(y.squeeze())
+        return self._memo("y", (id(self.y), id(self.output_transform)),
+                          lambda: np.atleast_1d(self.output_transform.forward(self.y, transforms_as="mean").squeeze()))
 
     @property
     def y_std_transformed(self):
@@ -475,7 +486,8 @@ class _ParamSpace:
             return -np.inf, np.zeros(self.dim)
         g, o = g_prior.copy(), 0
         for name, _, plate in self.items:
-            g[o : o + plate] += dx[o : o + plate] * np.broadcast_to(grads[name].reshape(-1), (plate,))
+            gv = grads[name].reshape(-1)
+            g[o : o + plate] += dx[o : o + plate] * (gv if gv.size == plate else np.broadcast_to(gv, (plate,)))
             o += plate
         return val, g
 
