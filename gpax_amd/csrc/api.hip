@@ -201,6 +201,33 @@ static int upload_small(gpx_handle* h, hipStream_t s, double* dst, const double*
   return GPX_OK;
 }
 
+// The same ring without the copy: the data is staged in a pinned slot that a kernel reads in place (pinned host memory is
+// device-addressable); the caller records the slot's event behind that kernel with stage_small_done.
+static int stage_small(gpx_handle* h, const double* src, int64_t count, const double** staged, int* slot) {
+  if (h->up_slot < count) {
+    GPX_HIP_CHECK(h, hipDeviceSynchronize());
+    if (h->h_up) (void)hipHostFree(h->h_up);
+    h->h_up = nullptr;
+    const int64_t sl = std::max<int64_t>(count, 64);
+    GPX_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_up), (size_t)(8 * sl) * sizeof(double), hipHostMallocDefault));
+    h->up_slot = sl;
+    for (auto& u : h->up_used) u = false;
+  }
+  const int i = h->up_next;
+  h->up_next = (i + 1) % 8;
+  if (!h->up_ev[i]) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->up_ev[i], hipEventDisableTiming));
+  if (h->up_used[i]) GPX_HIP_CHECK(h, hipEventSynchronize(h->up_ev[i]));
+  double* stage = h->h_up + (int64_t)i * h->up_slot;
+  memcpy(stage, src, (size_t)count * sizeof(double));
+  *staged = stage; *slot = i;
+  return GPX_OK;
+}
+static int stage_small_done(gpx_handle* h, hipStream_t s, int slot) {
+  GPX_HIP_CHECK(h, hipEventRecord(h->up_ev[slot], s));
+  h->up_used[slot] = true;
+  return GPX_OK;
+}
+
 #ifdef GPX_TIMELINE
 void tl_set_gemm(unsigned long long* p, unsigned long long* ends);
 void tl_set_potrf(unsigned long long* p);
@@ -1482,7 +1509,11 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
 
   const double* noise_dev; double noise_scalar;
   GPX_RET(upload_params(h, s, p, n, d, &noise_dev, &noise_scalar));
-  if (n <= 65536) GPX_RET(upload_small(h, s, h->d_r, y_minus_m, n));   // through the pinned ring: truly asynchronous
+  // small problems: the one-launch build below reads r straight from a pinned slot (and writes d_r on the way): no upload in the stream
+  const bool r_in_place = h->build_small && npad <= 256 && npad / nb < h->split_min_blocks;
+  const double* r_src = h->d_r; int r_slot = -1;
+  if (r_in_place) GPX_RET(stage_small(h, y_minus_m, n, &r_src, &r_slot));
+  else if (n <= 65536) GPX_RET(upload_small(h, s, h->d_r, y_minus_m, n));   // through the pinned ring: truly asynchronous
   else GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
   h->have_r = true;
 
@@ -1492,9 +1523,11 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
     const double T = (double)((n + 63) / 64);
     const double entries = T * (T + 1) / 2.0 * 4096.0;
     prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(p->kind, d) * entries, 8.0 * entries + 16.0 * n * d);
-    GPX_RET(launch_build_small(h, s, p->kind, h->d_x, nullptr, h->d_hyp, h->d_hyp + 2 * d, noise_dev, h->d_r, h->d_A, ld, n, npad, 0,
-                               npad, rows, d, p->apply_noise ? 1 : 0, h->d_info, nullptr, 0, npad + RZ, h->d_L + npad * ld));
+    GPX_RET(launch_build_small(h, s, p->kind, h->d_x, nullptr, h->d_hyp, h->d_hyp + 2 * d, noise_dev, r_src, h->d_A, ld, n, npad, 0,
+                               npad, rows, d, p->apply_noise ? 1 : 0, h->d_info, nullptr, 0, npad + RZ, h->d_L + npad * ld,
+                               r_slot >= 0 ? h->d_r : nullptr));
     prof_end(h, s);
+    if (r_slot >= 0) GPX_RET(stage_small_done(h, s, r_slot));
   }
   GramLaunch g;
   g.kind = p->kind; g.d = d; g.k_scale = 0.0; g.hyp = h->d_hyp; g.dev_scalars = h->d_hyp + 2 * d;

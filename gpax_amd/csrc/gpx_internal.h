@@ -71,7 +71,7 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& g);
 int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* xnew, const double* hyp,
                        const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
                        int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
-                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0 = -1, double* zero2 = nullptr);
+                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0 = -1, double* zero2 = nullptr, double* r_copy = nullptr);
 
 // C[M,N] = beta*C + alpha * A[M,K] * B[N,K]^T   (all row-major; K contiguous in A and B)
 struct GemmLaunch {

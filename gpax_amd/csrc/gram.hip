@@ -187,6 +187,7 @@ struct BuildArgs {
   int64_t n, npad, m_rows, r_row, rows_total;
   int d, diag_rule;
   int* zero_info; unsigned* zero_flags; int n_zero_flags;
+  double* r_copy;       // when set: the r row is also written here (r may then live in pinned host memory: no upload in the stream)
   int64_t ident_row0;   // >= 0: rows [ident_row0, ident_row0 + n) are identity rows (the gradient path's border: they become U = L^-T)
   double* zero2;        // when set: a second matrix (same ld) whose rows >= npad are cleared by the same launch (the border of L)
 };
@@ -206,7 +207,12 @@ __global__ void build_small_kernel(BuildArgs g) {
   if (row < g.n) { x1 = g.x + row * g.d; diag_row = g.diag_rule != 0; }
   else if (row < g.npad) { *dst = (row == col) ? 1.0 : 0.0; return; }
   else if (row < g.npad + g.m_rows) x1 = g.xnew + (row - g.npad) * g.d;
-  else if (row == g.r_row) { *dst = (col < g.n && g.r) ? g.r[col] : 0.0; return; }
+  else if (row == g.r_row) {
+    const double v = (col < g.n && g.r) ? g.r[col] : 0.0;
+    *dst = v;
+    if (g.r_copy && col < g.n) g.r_copy[col] = v;
+    return;
+  }
   else if (g.ident_row0 >= 0 && row >= g.ident_row0 && row < g.ident_row0 + g.n) { *dst = (col == row - g.ident_row0) ? 1.0 : 0.0; return; }
   else { *dst = 0.0; return; }
   if (col >= g.n) { *dst = 0.0; return; }
@@ -235,13 +241,13 @@ __global__ void build_small_kernel(BuildArgs g) {
 int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* xnew, const double* hyp,
                        const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
                        int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
-                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0, double* zero2) {
+                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0, double* zero2, double* r_copy) {
   if (npad > 256 || npad <= 0 || !dev_scalars) { gpx_set_error(h, "build_small: at most 256 columns"); return GPX_ERR_ARG; }
   BuildArgs g;
   g.x = x; g.xnew = xnew; g.hyp = hyp; g.dev_scalars = dev_scalars; g.noise = noise; g.r = r; g.out = out; g.ld = ld;
   g.n = n; g.npad = npad; g.m_rows = m_rows; g.r_row = r_row; g.rows_total = rows_total; g.d = d; g.diag_rule = diag_rule;
   g.zero_info = zero_info; g.zero_flags = zero_flags; g.n_zero_flags = n_zero_flags;
-  g.ident_row0 = ident_row0; g.zero2 = zero2;
+  g.ident_row0 = ident_row0; g.zero2 = zero2; g.r_copy = r_copy;
   const dim3 grid((unsigned)rows_total), block((unsigned)(npad <= 64 ? 64 : (npad <= 128 ? 128 : 256)));
   switch (kind) {
     case GPX_RBF: hipLaunchKernelGGL((build_small_kernel<GPX_RBF>), grid, block, 0, s, g); break;
