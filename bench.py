@@ -11,7 +11,9 @@ SURVEY.md section 8(d).
 Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the path shards
 over independent hyper-parameter draws (gpax's vmap over hp samples, gpax/gp.py:384-390):
 rank r factorises its own draw on its own GPU, no data-path collective, weak scaling.
-torch.distributed (gloo) is used only for the barrier and the max-over-ranks clock.
+torch.distributed (gloo, CPU tensors) is used only for the barrier and the max-over-ranks clock, and only
+when WORLD_SIZE > 1; torch.cuda is never touched (the library is loaded FIRST so that it binds the ROCm
+runtime it was built against and not PyTorch's bundled one -- gpx_runtime_info).
 
 Prints ONE JSON line (rank 0).
 """
@@ -61,18 +63,31 @@ def hp_draw(rank):
 
 
 def _committed_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected
-    in separate --pmc runs of this same command; profiles/r01_traffic.json), or None.  bench.py cannot
-    collect PMC counters itself."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per launch from the most recent committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected
+    in separate --pmc runs of this same command by tools/refresh_profiles.sh; profiles/rNN_traffic.json), or None.
+    bench.py cannot collect PMC counters itself (they need the profiler around the process).  Returns (bytes, file)."""
+    import glob
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                v = json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+            if v is not None:
+                return v, os.path.relpath(path, ROOT)
+        except (OSError, ValueError):
+            pass
+    return None, None
 
 
-def bench_distributed(args, rank, local_rank, world, dist, torch):
+def _max_over_ranks(dist, value):
+    import torch
+
+    t = torch.tensor([value], dtype=torch.float64)   # CPU tensor over gloo
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def bench_distributed(args, rank, local_rank, world, dist):
     """Config C4 family: one N x N factorisation distributed by block rows over the ranks (RCCL broadcast of
     the panel factor + all-gather of the panel column per step).  Strong scaling: the job is ONE fit+predict."""
     import gpax_amd
@@ -85,20 +100,18 @@ def bench_distributed(args, rank, local_rank, world, dist, torch):
     step = DistributedStep(x, x_new, y - 1.0, device=local_rank)
     for _ in range(args.warmup):
         step.fit_predict(params, np.ones(m), 0.0)
-    torch.cuda.synchronize()
+    step.core.synchronize()
     if dist:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        info, logp, mean, var = step.fit_predict(params, np.ones(m), 0.0)
-    torch.cuda.synchronize()
+        info, logp, mean, var = step.fit_predict(params, np.ones(m), 0.0)   # returns host results: the step is complete
+    step.core.synchronize()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = _max_over_ranks(dist, elapsed)
     assert info == 0 and np.isfinite(logp) and (var > 0).all()
     if rank == 0:
         print(json.dumps({
@@ -116,7 +129,7 @@ def bench_distributed(args, rank, local_rank, world, dist, torch):
         dist.destroy_process_group()
 
 
-def dist_leg(args, rank, local_rank, world, dist, torch, out):
+def dist_leg(args, rank, local_rank, world, dist, out):
     """Config C4 beside the headline number, at world size > 1 only: ONE N x N factorisation (default N=32768, d=8,
     M=1000) distributed row-block-cyclic over the ranks, RCCL broadcast of inv(L_kk) + all-gather of the panel per
     step (gpax_amd/csrc/dist.hip) -- strong scaling, timed like the main region (barrier, K steps, barrier, MAX over
@@ -141,16 +154,14 @@ def dist_leg(args, rank, local_rank, world, dist, torch, out):
         os.environ["GPX_DIST_EARLY_DIAG"] = "1" if early else "0"
         for _ in range(2):
             step.fit_predict(params, np.ones(m), 0.0)
-        torch.cuda.synchronize()
+        step.core.synchronize()
         dist.barrier()
         t0 = time.perf_counter()
         for _ in range(args.dist_steps):
             r = step.fit_predict(params, np.ones(m), 0.0)
-        torch.cuda.synchronize()
+        step.core.synchronize()
         dist.barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t.item()) / args.dist_steps * 1e3
+        ms = _max_over_ranks(dist, time.perf_counter() - t0) / args.dist_steps * 1e3
         return ms, r
 
     flops = n ** 3 / 3 + n * n * (m + 1)
@@ -211,11 +222,16 @@ def main():
     if world != args.gpus and world > 1:
         args.gpus = world
 
-    import torch  # plumbing only: device-wide synchronize + torch.distributed barrier / MAX
+    import gpax_amd  # raises if libgpx_hip.so is missing: no fallback.  Loaded BEFORE torch: binds /opt/rocm's HIP runtime
+    from gpax_amd import _lib as gpx_lib
+
+    rt_ok, rt_text = gpx_lib.runtime_info()
+    if not rt_ok:
+        raise SystemExit(f"bench.py: the HIP library resolved a foreign HIP runtime ({rt_text}); do not import torch before gpax_amd")
 
     dist = None
     if world > 1 or args.dist_rehearsal:
-        import torch.distributed as dist_mod
+        import torch.distributed as dist_mod   # control plane only (gloo, CPU tensors): barrier + MAX of the clocks
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -223,12 +239,9 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if os.environ.get("GPX_BENCH_ONE_DEVICE"):  # rehearsal of the multi-rank plumbing on a one-GPU box only
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-
-    import gpax_amd  # raises if libgpx_hip.so is missing: no fallback
 
     if args.workload == "dist":
-        return bench_distributed(args, rank, local_rank, world, dist, torch)
+        return bench_distributed(args, rank, local_rank, world, dist)
 
     core = gpax_amd.Core(local_rank)
     if args.nb:
@@ -247,8 +260,7 @@ def main():
         return core.fetch_results()  # logp, mean, var back on the host (16 KB), as _fast_predict returns them
 
     def sync():
-        core.synchronize()
-        torch.cuda.synchronize()
+        core.synchronize()   # every stream of the handle (the only GPU work of this process)
 
     for _ in range(args.warmup):
         step()
@@ -263,9 +275,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = _max_over_ranks(dist, elapsed)
     assert info == 0 and np.isfinite(logp) and np.isfinite(mean).all() and (var > 0).all()
 
     ms_per_step = elapsed / args.steps * 1e3
@@ -289,6 +299,7 @@ def main():
             "n": n, "d": d, "m": m, "nb": core.get_option("nb"),
             "parallelism": f"hp-draw x{world} (independent factorisations, no collective)",
         },
+        "hip_runtime": rt_text,
     }
 
     if rank == 0:
@@ -309,14 +320,25 @@ def main():
         avg_s = tr["ms"] * 1e-3 / max(tr["launches"], 1)
         flops_per_launch = tr["flops"] / max(tr["launches"], 1)
         achieved = flops_per_launch / avg_s * 1e-12 if avg_s > 0 else 0.0
+        # both ceilings of this kernel, stated: the MFMA peak, and the HBM roof at its ALGORITHMIC intensity (every C entry
+        # read and written once, the panel read once per launch): at K = nb = 128 that is ~16 flop/B, i.e. the kernel sits
+        # near the ridge (78.6 TFLOP/s / 8 TB/s = 9.8 flop/B) and above it only by the factor shown
+        bytes_per_launch = tr["bytes"] / max(tr["launches"], 1)
+        intensity = flops_per_launch / bytes_per_launch if bytes_per_launch > 0 else 0.0
+        hbm_roof = intensity * HBM_PEAK_GBS * 1e-3
+        traffic, traffic_src = _committed_traffic("trailing_update")
         out["roofline"] = {
             "kernel": "gemm_nt_kernel (trailing SYRK/GEMM update, v_mfma_f64_16x16x4_f64)",
-            "bound": "mfma",
+            "bound": "mfma" if hbm_roof >= FP64_MFMA_PEAK_TFLOPS else "hbm",
             "achieved": achieved,
             "peak": FP64_MFMA_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-            "traffic": _committed_traffic("trailing_update"),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
+            "ceilings": {"mfma_tflops": FP64_MFMA_PEAK_TFLOPS, "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "algorithmic_flop_per_byte": intensity, "hbm_roof_tflops_at_8TBps": hbm_roof,
+                         "hbm_roof_tflops_at_measured_traffic": (flops_per_launch / traffic * HBM_PEAK_GBS * 1e-3) if traffic else None},
             "peak_measured": FP64_MFMA_MEASURED_TFLOPS,
             "frac_of_measured_peak": achieved / FP64_MFMA_MEASURED_TFLOPS,
             "launches_per_step": tr["launches"] / args.steps,
@@ -333,7 +355,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": (g_bytes / g_avg * 1e-9 / HBM_PEAK_GBS) if g_avg > 0 else 0.0,
-            "traffic": _committed_traffic("gram"),
+            "traffic": _committed_traffic("gram")[0],
             "avg_launch_us": g_avg * 1e6,
         }
         out["ms_per_step_profiled"] = prof_ms_per_step
@@ -349,30 +371,98 @@ def main():
             core.profile_mode(0)
 
         if not args.no_sweep and world == 1 and args.n == 4096:
-            # ---- the other sizes BASELINE.json's metric is quoted on (N in 1k..32k, same d and M), a few steps each,
-            # outside the headline region: points/s and the whole step's fp64 rate (N^3/3 + N^2 (M+1) flops)
-            sweep = []
-            for ns in (1024, 2048, 8192, 16384, 32768):
-                xs, ys, xns = synthetic_problem(ns, d, m, seed=0)
-                core.set_train(xs)
-                core.set_test(xns)
-                core.set_targets(ys - 1.0, np.ones(m))
-                reps = 20 if ns <= 2048 else (5 if ns <= 8192 else 2)
+            # ---- the other sizes BASELINE.json's metric is quoted on (N in 1k..32k, same d and M) and its other single-GPU
+            # configs (C1, C3, C5), a few steps each, outside the headline region: points/s and the whole step's fp64 rate
+            # (N^3/3 + N^2 (M+1) flops)
+            def timed_steps(reps):
                 for _ in range(2):
                     step()
                 sync()
                 t3 = time.perf_counter()
                 for _ in range(reps):
-                    info_s, logp_s, mean_s, var_s = step()
+                    r = step()
                 sync()
-                ms = (time.perf_counter() - t3) / reps * 1e3
+                return (time.perf_counter() - t3) / reps * 1e3, r
+
+            def load(xs, ys_minus_m, xns, m_new):
+                core.set_train(xs)
+                core.set_test(xns)
+                core.set_targets(ys_minus_m, m_new)
+
+            sweep = []
+            for ns in (1024, 2048, 8192, 16384, 32768):
+                xs, ys, xns = synthetic_problem(ns, d, m, seed=0)
+                load(xs, ys - 1.0, xns, np.ones(m))
+                ms, (info_s, logp_s, mean_s, var_s) = timed_steps(20 if ns <= 2048 else (5 if ns <= 8192 else 2))
                 sweep.append({"n": ns, "ms_per_step": ms, "points_per_s": ns / (ms * 1e-3),
                               "step_tflops": (ns ** 3 / 3 + ns * ns * (m + 1)) / (ms * 1e-3) * 1e-12,
                               "ok": bool(info_s == 0 and np.isfinite(logp_s) and (var_s > 0).all())})
             out["sweep"] = sweep
-            core.set_train(x)   # back to the headline problem for the CPU comparison below
-            core.set_test(x_new)
-            core.set_targets(y - 1.0, np.ones(m))
+
+            # BASELINE.json configs[0], [2], [4] (C1, C3, C5; C4 is the multi-GPU leg).  C5: structured (piecewise power-law)
+            # prior mean on x[:,0] (examples/04_Structured_GP.ipynb cell 10), EI over 10 000 candidates (gpax/acquisition.py:291-298)
+            def piecewise(xx, t=1.7, b1=4.5, b2=2.5):
+                return np.where(xx[:, 0] < t, xx[:, 0] ** b1, xx[:, 0] ** b2 * t ** (b1 - b2))
+
+            cfgs = []
+            params_save = params
+            for name, kind_c, nc, dc, mc in (("C1", gpax_amd.RBF, 256, 1, 100), ("C3", gpax_amd.MATERN52, 16384, 16, 1000),
+                                             ("C5", gpax_amd.MATERN52, 8192, 2, 10000)):
+                rng_c = np.random.default_rng(7)
+                if name == "C5":
+                    xs = rng_c.uniform(0.0, 3.0, (nc, dc)); xns = rng_c.uniform(0.0, 3.0, (mc, dc))
+                    ys = piecewise(xs) + 0.05 * rng_c.standard_normal(nc)
+                    load(xs, ys - piecewise(xs), xns, piecewise(xns))
+                    params = gpax_amd.make_params(kind_c, 1.0, 1.0, None, np.array([0.01]), 1e-6, True)
+                else:
+                    xs, ys, xns = synthetic_problem(nc, dc, mc, seed=0)
+                    load(xs, ys - 1.0, xns, np.ones(mc))
+                    params = gpax_amd.make_params(kind_c, 1.0, 1.0, None, np.array([k_noise]), 1e-6, True)
+                ms, (info_s, logp_s, mean_s, var_s) = timed_steps(20 if nc <= 2048 else 3)
+                rec = {"config": name, "kernel": "rbf" if kind_c == gpax_amd.RBF else "matern52", "n": nc, "d": dc, "m": mc,
+                       "ms_per_step": ms, "points_per_s": nc / (ms * 1e-3),
+                       "step_tflops": (nc ** 3 / 3 + nc * nc * (mc + 1)) / (ms * 1e-3) * 1e-12,
+                       "ok": bool(info_s == 0 and np.isfinite(logp_s) and (var_s > 0).all())}
+                if name == "C5":   # the acquisition: analytic EI over all candidates from (mu, sd) of ONE posterior call
+                    from math import pi, sqrt
+
+                    from scipy.special import ndtr
+
+                    t4 = time.perf_counter()
+                    sd = np.sqrt(var_s)
+                    u = (mean_s - ys.max()) / sd
+                    ei = sd * np.exp(-0.5 * u * u) / sqrt(2 * pi) + (mean_s - ys.max()) * ndtr(u)
+                    rec["ei_host_ms"] = (time.perf_counter() - t4) * 1e3
+                    rec["ei_argmax"] = int(np.argmax(ei))
+                    rec["ok"] = rec["ok"] and bool(np.isfinite(ei).all())
+                cfgs.append(rec)
+            out["configs"] = cfgs
+            params = params_save
+
+            # ---- batched hyper-parameter draws (gpax's vmap over hp samples, gpax/gp.py:354-364, 384-390): B draws in ONE
+            # schedule (gpx_fit_predict_batch), inputs and per-draw targets uploaded per call (they differ per draw)
+            batched = []
+            for nb_, B in ((256, 32), (1024, 16), (4096, 8), (4096, 16)):
+                xs, ys, xns = synthetic_problem(nb_, d, m, seed=0)
+                core.set_train(xs)
+                core.set_test(xns)
+                rngb = np.random.default_rng(1)
+                plist = [gpax_amd.make_params(kind, float(np.exp(0.3 * rngb.standard_normal())), float(np.exp(0.3 * rngb.standard_normal())),
+                                              None, np.array([k_noise]), 1e-6, True) for _ in range(B)]
+                rb = np.stack([ys - 1.0] * B)
+                mb = np.ones((B, m))
+                for _ in range(2):
+                    core.fit_predict_batch(plist, rb, mb, None)
+                reps = 10 if nb_ <= 1024 else 4
+                t5 = time.perf_counter()
+                for _ in range(reps):
+                    info_b, logp_b, mean_b, var_b = core.fit_predict_batch(plist, rb, mb, None)
+                ms = (time.perf_counter() - t5) / reps * 1e3
+                batched.append({"B": B, "n": nb_, "ms_per_batch": ms, "points_per_s": nb_ * B / (ms * 1e-3),
+                                "step_tflops": B * (nb_ ** 3 / 3 + nb_ * nb_ * (m + 1)) / (ms * 1e-3) * 1e-12,
+                                "ok": bool((info_b == 0).all() and np.isfinite(logp_b).all() and (var_b > 0).all())})
+            out["batched"] = batched
+            load(x, y - 1.0, x_new, np.ones(m))   # back to the headline problem for the CPU comparison below
 
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
             # ---- CPU baseline: the oracle (NumPy/SciPy port of the reference formulae; the reference's
@@ -452,11 +542,11 @@ def main():
                 if rank == 0:
                     out.setdefault("dist_c4", {})["error"] = f"not finished within {args.dist_timeout:.0f} s"
                     print(json.dumps(out), flush=True)
-                os._exit(0)
+                os._exit(3)   # a leg that hangs is a failure of the run, whatever was printed: never rc 0
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            dist_leg(args, rank, local_rank, world, dist, torch, out)
+            dist_leg(args, rank, local_rank, world, dist, out)
         except Exception as exc:  # noqa: BLE001 -- reported, never fatal for the headline line
             out.setdefault("dist_c4", {})["error"] = f"{type(exc).__name__}: {exc}"
         try:   # a rank that failed alone would leave the others in a collective: meet here or let the watchdog end it

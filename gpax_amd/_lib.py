@@ -24,7 +24,9 @@ ERR_NAMES = {
     -4: "GPX_ERR_NOMEM",
     -5: "GPX_ERR_COMM",
     -6: "GPX_ERR_UNSUPPORTED",
+    -7: "GPX_ERR_RETRY",
 }
+ERR_RETRY = -7
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libgpx_hip.so")
 
@@ -76,6 +78,10 @@ SIGNATURES = {
     "gpx_set_targets": (C.c_int, [C.c_void_p, _dp, _dp]),
     "gpx_fit_predict_async": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), C.c_double]),
     "gpx_fetch_results": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "gpx_fit_predict_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(KernelParams), _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int32)]),
+    "gpx_sample_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(KernelParams), _dp, _dp, _dp, _dp, C.c_int64, C.c_int32,
+                                   _dp, _dp, _dp, C.POINTER(C.c_int32)]),
+    "gpx_runtime_info": (C.c_int, [C.c_char_p, C.c_int]),
     "gpx_profile_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "gpx_profile_reset": (C.c_int, [C.c_void_p]),
     "gpx_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -118,14 +124,36 @@ def load():
             "gpax_amd has no CPU fallback."
         )
     lib = C.CDLL(LIB_PATH)
+    compat = bool(os.environ.get("GPX_LIB_COMPAT"))   # tools only: A/B an older build of the library (tools/bits_r1.py, tools/ab_lib.py)
     for name, (res, args) in SIGNATURES.items():
+        if compat and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.gpx_abi_version() != 1:
+    if lib.gpx_abi_version() != 2 and not compat:
         raise GpxError("libgpx_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def runtime_info():
+    """``(ok, text)``: which HIP runtime the library resolved to in this process (``gpx_runtime_info``).  ``ok`` is False
+    when it is not the major.minor the library was compiled against -- the case when PyTorch, with its bundled
+    ``libamdhip64.so`` of another ROCm release, was imported first."""
+    buf = C.create_string_buffer(1024)
+    rc = load().gpx_runtime_info(buf, 1024)
+    return rc == 0, buf.value.decode()
+
+
+def make_params_batch(param_list):
+    """An array of ``gpx_kernel_params`` for the batched entry points from a list of ``make_params`` results."""
+    arr = (KernelParams * len(param_list))()
+    keep = []
+    for i, (p, k) in enumerate(param_list):
+        arr[i] = p
+        keep.append(k)
+    return arr, keep
 
 
 def _arr(x, shape=None):
@@ -180,6 +208,7 @@ class Core:
         self._h = h
         self.n = self.m = self.d = 0
         self._gp_owner = self._gp_test = self._gp_factor = None  # bookkeeping of gpax_amd.gp
+        self._async = None   # (params, new_noise) of the step in flight: re-issued when a hand-over timed out
 
     # -- plumbing
     def close(self):
@@ -336,14 +365,66 @@ class Core:
 
     def fit_predict_async(self, params, new_noise=0.0):
         p, _keep = params
+        self._async = (params, float(new_noise))
         self._check(self._lib.gpx_fit_predict_async(self._h, C.byref(p), float(new_noise)), "gpx_fit_predict_async")
 
     def fetch_results(self):
         logp = C.c_double()
         mean = np.empty(self.m)
         var = np.empty(self.m)
-        info = self._check(self._lib.gpx_fetch_results(self._h, C.byref(logp), _ptr(mean), _ptr(var)), "gpx_fetch_results")
+        rc = self._lib.gpx_fetch_results(self._h, C.byref(logp), _ptr(mean), _ptr(var))
+        if rc == ERR_RETRY and self._async is not None:
+            # an in-kernel hand-over timed out (dispatches serialised or CUs contended): the handle now hands over at
+            # kernel boundaries; the step is issued again, once, in this process
+            params, new_noise = self._async
+            self._check(self._lib.gpx_fit_predict_async(self._h, C.byref(params[0]), new_noise), "gpx_fit_predict_async (retry)")
+            rc = self._lib.gpx_fetch_results(self._h, C.byref(logp), _ptr(mean), _ptr(var))
+        info = self._check(rc, "gpx_fetch_results")
         return info, logp.value, mean, var
+
+    # -- batched hyper-parameter draws (gpax's vmap over hp samples, gpax/gp.py:354-364,384-390)
+    def fit_predict_batch(self, param_list, y_minus_m, m_new=None, new_noise=None):
+        """``gpx_fit_predict_batch``: B draws in one schedule.  ``param_list``: B ``make_params`` results;
+        ``y_minus_m`` (B, n); ``m_new`` (B, m) or None; ``new_noise`` (B,) or None.
+        Returns ``(info (B,), logp (B,), mean (B, m), var (B, m))``."""
+        B = len(param_list)
+        arr, _keep = make_params_batch(param_list)
+        r = _arr(y_minus_m).reshape(B, -1)
+        if r.shape[1] != self.n:
+            raise ValueError("y_minus_m must be (B, n)")
+        mn = _arr(m_new).reshape(B, self.m) if m_new is not None else None
+        nn = _arr(new_noise).reshape(B) if new_noise is not None else None
+        logp, mean, var = np.empty(B), np.empty((B, self.m)), np.empty((B, self.m))
+        info = np.zeros(B, dtype=np.int32)
+        self._check(
+            self._lib.gpx_fit_predict_batch(self._h, B, arr, _ptr(r), _ptr(mn), _ptr(nn), _ptr(logp), _ptr(mean), _ptr(var),
+                                            info.ctypes.data_as(C.POINTER(C.c_int32))),
+            "gpx_fit_predict_batch",
+        )
+        return info, logp, mean, var
+
+    def sample_batch(self, param_list, y_minus_m, m_new, new_noise, eps, conditioned=True):
+        """``gpx_sample_batch``: per draw the posterior (or prior) mean, sd = sqrt(diag cov) and ``mean + eps chol(cov)^T``
+        with the covariance kept in HBM.  ``eps`` (B, nsamp, m).  Returns ``(info (B,), mean (B, m), sd (B, m),
+        samples (B, nsamp, m))``."""
+        B = len(param_list)
+        arr, _keep = make_params_batch(param_list)
+        eps = _arr(eps)
+        if eps.ndim != 3 or eps.shape[0] != B or eps.shape[2] != self.m:
+            raise ValueError("eps must be (B, nsamp, m)")
+        r = _arr(y_minus_m).reshape(B, -1) if y_minus_m is not None else None
+        if conditioned and (r is None or r.shape[1] != self.n):
+            raise ValueError("y_minus_m must be (B, n)")
+        mn = _arr(m_new).reshape(B, self.m) if m_new is not None else None
+        nn = _arr(new_noise).reshape(B) if new_noise is not None else None
+        mean, sd, out = np.empty((B, self.m)), np.empty((B, self.m)), np.empty_like(eps)
+        info = np.zeros(B, dtype=np.int32)
+        self._check(
+            self._lib.gpx_sample_batch(self._h, B, arr, _ptr(r), _ptr(mn), _ptr(nn), _ptr(eps), eps.shape[1], 1 if conditioned else 0,
+                                       _ptr(mean), _ptr(sd), _ptr(out), info.ctypes.data_as(C.POINTER(C.c_int32))),
+            "gpx_sample_batch",
+        )
+        return info, mean, sd, out
 
     # -- measurement
     def profile_mode(self, mode):

@@ -2,6 +2,7 @@
 // the bordered right-looking blocked Cholesky with two-stream look-ahead, the
 // solves against a cached factor, and the measurement hooks.
 
+#include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,65 +16,12 @@ static std::string g_create_error;
 
 static std::mutex g_err_mutex;
 
-void HostWorker::start(int device) {
-  if (started) return;
-  started = true;
-  th = std::thread([this, device]() {
-    (void)hipSetDevice(device);
-    for (;;) {
-      int spins = 0;
-      while (state.load(std::memory_order_acquire) == 0) {   // poll ~0.3 ms for the next job, then sleep
-        if (++spins > 20000) {
-          std::unique_lock<std::mutex> lk(m);
-          cv.wait(lk, [this] { return state.load(std::memory_order_acquire) != 0; });
-          break;
-        }
-      }
-      if (state.load(std::memory_order_acquire) == 3) return;
-      state.store(2, std::memory_order_release);
-      job();
-      state.store(0, std::memory_order_release);
-    }
-  });
-}
-void HostWorker::post(std::function<void()> f) {
-  job = std::move(f);
-  { std::lock_guard<std::mutex> lk(m); state.store(1, std::memory_order_release); }
-  cv.notify_one();
-}
-void HostWorker::wait() {
-  while (state.load(std::memory_order_acquire) != 0) { }
-}
-void HostWorker::stop() {
-  if (!started) return;
-  wait();
-  { std::lock_guard<std::mutex> lk(m); state.store(3, std::memory_order_release); }
-  cv.notify_one();
-  th.join();
-  started = false;
-}
-
 void gpx_set_error(gpx_handle* h, const std::string& msg) {
   std::lock_guard<std::mutex> lk(g_err_mutex);
   if (h) h->err = msg; else g_create_error = msg;
 }
 
 // --------------------------------------------------------------------------- memory
-
-template <typename T>
-static int ensure(gpx_handle* h, T** p, int64_t* cap, int64_t count) {
-  if (count <= *cap && *p) return GPX_OK;
-  if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
-  if (count <= 0) count = 1;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
-  if (e != hipSuccess) {
-    gpx_set_error(h, std::string("hipMalloc failed: ") + hipGetErrorString(e));
-    *p = nullptr;
-    return GPX_ERR_NOMEM;
-  }
-  *cap = count;
-  return GPX_OK;
-}
 
 // ------------------------------------------------------------------------ profiling
 
@@ -144,27 +92,30 @@ static int prof_collect(gpx_handle* h) {
 // ---- the result block and its one-copy fetch
 #define GPX_OUT_HEAD 10   // doubles in front of mean: scal[8], then 4 ints of info
 
-// (Re)allocate the result block for `count` doubles of mean + var; the head (scal, info) survives a growth.
-static int ensure_out(gpx_handle* h, int64_t count) {
-  if (h->d_out && h->out_cap >= count) return GPX_OK;
+// (Re)allocate the result block for `batch` draws with `tail` doubles (mean + var, or alpha + sums) behind each head; the
+// head of draw 0 (scal, info) survives a growth.  Sets the per-draw stride s_out.
+static int ensure_out(gpx_handle* h, int64_t tail, int batch = 1) {
+  const int64_t stride = round_up(GPX_OUT_HEAD + std::max<int64_t>(tail, 2), 2), need = stride * batch;
+  h->s_out = stride;
+  if (h->d_out && h->out_cap >= need) return GPX_OK;
   double* nw = nullptr;
-  GPX_HIP_CHECK(h, hipMalloc(reinterpret_cast<void**>(&nw), (size_t)(GPX_OUT_HEAD + count) * sizeof(double)));
+  GPX_HIP_CHECK(h, hipMalloc(reinterpret_cast<void**>(&nw), (size_t)need * sizeof(double)));
+  GPX_HIP_CHECK(h, hipDeviceSynchronize());
+  GPX_HIP_CHECK(h, hipMemset(nw, 0, (size_t)need * sizeof(double)));
   if (h->d_out) {
-    GPX_HIP_CHECK(h, hipDeviceSynchronize());
     GPX_HIP_CHECK(h, hipMemcpy(nw, h->d_out, GPX_OUT_HEAD * sizeof(double), hipMemcpyDeviceToDevice));
     (void)hipFree(h->d_out);
-  } else {
-    GPX_HIP_CHECK(h, hipMemset(nw, 0, GPX_OUT_HEAD * sizeof(double)));
   }
-  h->d_out = nw; h->out_cap = count;
+  h->d_out = nw; h->out_cap = need;
   h->d_scal = nw; h->d_info = reinterpret_cast<int*>(nw + 8); h->d_mean = nw + GPX_OUT_HEAD; h->d_var = h->d_mean + 1;
   return GPX_OK;
 }
 
-// One device-to-host copy (into pinned memory) of [scal | info | first `tail` doubles after the head], then a
-// stream sync.  Returns a pointer to the pinned copy: scal at [0], info at ((int*)(p + 8))[0], mean at p + 10.
-static int fetch_block(gpx_handle* h, int64_t tail, const double** out) {
-  const int64_t cnt = GPX_OUT_HEAD + tail;
+// One device-to-host copy (into pinned memory) of [scal | info | first `tail` doubles after the head] (of every draw of a
+// batch: `batch` blocks of s_out doubles), then a stream sync.  Returns a pointer to the pinned copy: scal at [0], info at
+// ((int*)(p + 8))[0], mean at p + 10; draw b at p + b * s_out.
+static int fetch_block(gpx_handle* h, int64_t tail, const double** out, int batch = 1) {
+  const int64_t cnt = batch > 1 ? h->s_out * batch : GPX_OUT_HEAD + tail;
   if (h->pinned_cap < cnt) {
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     h->h_pinned = nullptr; h->pinned_cap = 0;
@@ -260,39 +211,15 @@ extern "C" long long gpx_timeline_read(unsigned long long* out, long long max_re
 
 extern "C" int gpx_abi_version(void) { return GPX_ABI_VERSION; }
 
-// Three streams.  s_main carries the critical path (diagonal block, panel solve, near look-ahead) at
-// the highest priority on all CUs.  s_far (far look-ahead) and s_trail (bulk trailing update) may be
-// put on a CU mask that leaves GPX_RESERVED_CUS CUs untouched (default 0 = no mask: measured no gain
-// once the bulk kernel is released only after the near look-ahead has been queued, see factor_loop).
+// Four streams: P (s_main) and P2 (s_main2) carry the chain at the highest priority, Q (s_far) the panels and
+// look-ahead columns, T (s_trail) the bulk updates at the lowest.  (CU masks that keep T off a few CUs for the
+// chain were measured in round 1 and cost more than they return: N = 32768 228.5 -> 237 ms; removed.)
 static hipError_t create_streams(gpx_handle* h) {
   int lo = 0, hi = 0;
   hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
   if (e != hipSuccess) return e;
   if ((e = hipStreamCreateWithPriority(&h->s_main, hipStreamNonBlocking, hi)) != hipSuccess) return e;
   if ((e = hipStreamCreateWithPriority(&h->s_main2, hipStreamNonBlocking, hi)) != hipSuccess) return e;
-  const char* env = getenv("GPX_RESERVED_CUS");
-  const int ncu = h->prop.multiProcessorCount;
-  int drop = env ? atoi(env) : 0;   // measured: no gain once the bulk kernel is released after the near look-ahead
-  if (drop > 0 && drop < ncu) {
-    // Mask bit i is CU i/8 of XCD i%8 (measured: excluding every 16th bit halves ONE XCD and the bulk kernel, whose
-    // workgroups are dealt round-robin over the XCDs, slows to that XCD's pace).  The first `drop` bits (a multiple
-    // of 8) therefore take drop/8 CUs from every XCD.  GPX_RESERVED_SPREAD=1: the old every-(ncu/drop)-th rule.
-    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    const bool spread = getenv("GPX_RESERVED_SPREAD") && atoi(getenv("GPX_RESERVED_SPREAD")) != 0;
-    if (!spread) drop = (drop + 7) / 8 * 8;
-    for (int i = 0; i < ncu; ++i) {
-      const bool excluded = spread ? ((int64_t)i * drop / ncu) != ((int64_t)(i + 1) * drop / ncu) : i < drop;
-      if (!excluded) mask[(size_t)i / 32] |= 1u << (i % 32);
-    }
-    // only the bulk stream T is kept off the reserved CUs (GPX_RESERVED_Q=1: the panel stream Q too)
-    const bool mask_q = getenv("GPX_RESERVED_Q") && atoi(getenv("GPX_RESERVED_Q")) != 0;
-    hipError_t e1 = hipExtStreamCreateWithCUMask(&h->s_trail, (uint32_t)mask.size(), mask.data());
-    hipError_t e2 = mask_q ? hipExtStreamCreateWithCUMask(&h->s_far, (uint32_t)mask.size(), mask.data())
-                           : hipStreamCreateWithPriority(&h->s_far, hipStreamNonBlocking, hi);
-    if (e1 == hipSuccess && e2 == hipSuccess) return hipSuccess;
-    if (e1 == hipSuccess) { (void)hipStreamDestroy(h->s_trail); h->s_trail = nullptr; }
-    if (e2 == hipSuccess) { (void)hipStreamDestroy(h->s_far); h->s_far = nullptr; }
-  }
   if ((e = hipStreamCreateWithPriority(&h->s_far, hipStreamNonBlocking, hi)) != hipSuccess) return e;
   return hipStreamCreateWithPriority(&h->s_trail, hipStreamNonBlocking, lo);
 }
@@ -326,28 +253,10 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
     delete h;
     return GPX_ERR_UNSUPPORTED;
   }
-  const char* env;
-  if ((env = getenv("GPX_NB"))) { h->nb = atoi(env) == 64 ? 64 : 128; h->nb_auto = false; }
-  if ((env = getenv("GPX_LOOKAHEAD"))) h->lookahead = atoi(env) != 0;
-  if ((env = getenv("GPX_GRAPH"))) h->use_graph = atoi(env) != 0;
-  if ((env = getenv("GPX_DEPTH"))) h->depth = std::min(std::max(atoi(env), 1), 3);
-  if ((env = getenv("GPX_PAIR_MIN"))) h->pair_min = std::max(atoi(env), 0);
-  if ((env = getenv("GPX_QUAD_MIN"))) h->quad_min = std::max(atoi(env), 0);
-  if ((env = getenv("GPX_LA_ROWS"))) h->la_rows = std::max(atoi(env), 0);
-  if ((env = getenv("GPX_COL_SPLIT"))) h->col_split = std::max(atoi(env), 0);
-  if ((env = getenv("GPX_NEAR_BLOCK"))) h->near_block = atoi(env) != 0;
-  if ((env = getenv("GPX_FUSE_BAND"))) h->fuse_band = atoi(env) != 0;
-  if ((env = getenv("GPX_BORDER_SIDE"))) h->border_side = atoi(env) != 0;
-  if ((env = getenv("GPX_DIAG_BAND"))) h->diag_band = atoi(env) != 0;
-  if ((env = getenv("GPX_LP_FLAG"))) h->lp_flag = atoi(env) != 0;
-  if ((env = getenv("GPX_EPI_SPLIT"))) h->epi_split = atoi(env) != 0;
-  if ((env = getenv("GPX_POTRF_PERSIST"))) h->potrf_persist = atoi(env) != 0;
-  if ((env = getenv("GPX_BUILD_SMALL"))) h->build_small = atoi(env) != 0;
-  if ((env = getenv("GPX_SPLIT_MIN_BLOCKS"))) h->split_min_blocks = std::max(atoi(env), 2);
-  if ((env = getenv("GPX_HOST_THREADS"))) h->host_threads = atoi(env) >= 2 ? 2 : 1;
   // in-kernel hand-overs need the chain's kernels to run CONCURRENTLY; hardware-counter collection
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
   if (getenv("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS")) h->resident = 0;
+  const char* env;
   if ((env = getenv("GPX_RESIDENT"))) h->resident = std::min(std::max(atoi(env), 0), 2);
   *out = h;
   return GPX_OK;
@@ -356,17 +265,15 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
 extern "C" int gpx_destroy(gpx_handle* h) {
   if (!h) return GPX_OK;
   (void)hipSetDevice(h->device);
-  h->worker.stop();
   (void)hipDeviceSynchronize();
   gpx_dist_free(h);
   void* bufs[] = {h->d_x, h->d_xnew, h->d_r, h->d_mnew, h->d_hyp, h->d_noise, h->d_A, h->d_L, h->d_W,
                   h->d_S, h->d_cov, h->d_z, h->d_out, h->d_g1, h->d_g2,
-                  h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2, h->d_kinv, h->d_gpart, h->d_mini};
+                  h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2, h->d_kinv, h->d_gpart, h->d_mini, h->d_eps, h->d_smp};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->h_up) (void)hipHostFree(h->h_up);
   for (auto e : h->up_ev) if (e) (void)hipEventDestroy(e);
-  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
   for (auto e : h->ev_far) (void)hipEventDestroy(e);
@@ -403,6 +310,17 @@ extern "C" int gpx_synchronize(gpx_handle* h) {
   return GPX_OK;
 }
 
+static int* option_slot(gpx_handle* h, const char* name) {
+  if (!strcmp(name, "lookahead")) return &h->lookahead;
+  if (!strcmp(name, "resident")) return &h->resident;
+  if (!strcmp(name, "pair_min")) return &h->pair_min;
+  if (!strcmp(name, "quad_min")) return &h->quad_min;
+  if (!strcmp(name, "split_min_blocks")) return &h->split_min_blocks;
+  if (!strcmp(name, "la_rows")) return &h->la_rows;
+  if (!strcmp(name, "debug_force_timeout")) return &h->debug_force_timeout;
+  return nullptr;
+}
+
 extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!h || !name) return GPX_ERR_ARG;
   if (!strcmp(name, "nb")) {
@@ -412,96 +330,88 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
     if (h->nb != nv) { h->nb = nv; h->have_factor = false; }
     return GPX_OK;
   }
-  if (!strcmp(name, "lookahead")) { h->lookahead = value != 0; return GPX_OK; }
-  if (!strcmp(name, "graph")) { h->use_graph = value != 0; return GPX_OK; }
-  if (!strcmp(name, "depth")) { h->depth = (int)std::min<int64_t>(std::max<int64_t>(value, 1), 3); return GPX_OK; }
-  if (!strcmp(name, "pair_min")) { h->pair_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
-  if (!strcmp(name, "quad_min")) { h->quad_min = (int)std::max<int64_t>(value, 0); return GPX_OK; }
-  if (!strcmp(name, "la_rows")) { h->la_rows = (int)std::max<int64_t>(value, 0); return GPX_OK; }
-  if (!strcmp(name, "col_split")) { h->col_split = (int)std::max<int64_t>(value, 0); return GPX_OK; }
-  if (!strcmp(name, "near_block")) { h->near_block = value != 0; return GPX_OK; }
-  if (!strcmp(name, "fuse_band")) { h->fuse_band = value != 0; return GPX_OK; }
-  if (!strcmp(name, "border_side")) { h->border_side = value != 0; return GPX_OK; }
-  if (!strcmp(name, "diag_band")) { h->diag_band = value != 0; return GPX_OK; }
-  if (!strcmp(name, "lp_flag")) { h->lp_flag = value != 0; return GPX_OK; }
-  if (!strcmp(name, "epi_split")) { h->epi_split = value != 0; return GPX_OK; }
-  if (!strcmp(name, "potrf_persist")) { h->potrf_persist = value != 0; return GPX_OK; }
-  if (!strcmp(name, "build_small")) { h->build_small = value != 0; return GPX_OK; }
-  if (!strcmp(name, "split_min_blocks")) { h->split_min_blocks = (int)std::max<int64_t>(value, 2); return GPX_OK; }
-  if (!strcmp(name, "host_threads")) { h->host_threads = value >= 2 ? 2 : 1; return GPX_OK; }
-  if (!strcmp(name, "resident")) { h->resident = (int)std::min<int64_t>(std::max<int64_t>(value, 0), 2); return GPX_OK; }
-  gpx_set_error(h, std::string("unknown option ") + name);
-  return GPX_ERR_ARG;
+  int* slot = option_slot(h, name);
+  if (!slot) { gpx_set_error(h, std::string("unknown option ") + name); return GPX_ERR_ARG; }
+  int64_t v = std::max<int64_t>(value, 0);
+  if (!strcmp(name, "lookahead") || !strcmp(name, "debug_force_timeout")) v = v != 0;
+  if (!strcmp(name, "resident")) v = std::min<int64_t>(v, 2);
+  if (!strcmp(name, "split_min_blocks")) v = std::max<int64_t>(v, 2);
+  *slot = (int)v;
+  return GPX_OK;
 }
 
 extern "C" int gpx_get_option(gpx_handle* h, const char* name, int64_t* value) {
   if (!h || !name || !value) return GPX_ERR_ARG;
   if (!strcmp(name, "nb")) { *value = h->nb; return GPX_OK; }
-  if (!strcmp(name, "lookahead")) { *value = h->lookahead; return GPX_OK; }
-  if (!strcmp(name, "graph")) { *value = h->use_graph; return GPX_OK; }
-  if (!strcmp(name, "depth")) { *value = h->depth; return GPX_OK; }
-  if (!strcmp(name, "pair_min")) { *value = h->pair_min; return GPX_OK; }
-  if (!strcmp(name, "quad_min")) { *value = h->quad_min; return GPX_OK; }
-  if (!strcmp(name, "la_rows")) { *value = h->la_rows; return GPX_OK; }
-  if (!strcmp(name, "col_split")) { *value = h->col_split; return GPX_OK; }
-  if (!strcmp(name, "near_block")) { *value = h->near_block; return GPX_OK; }
-  if (!strcmp(name, "fuse_band")) { *value = h->fuse_band; return GPX_OK; }
-  if (!strcmp(name, "border_side")) { *value = h->border_side; return GPX_OK; }
-  if (!strcmp(name, "diag_band")) { *value = h->diag_band; return GPX_OK; }
-  if (!strcmp(name, "lp_flag")) { *value = h->lp_flag; return GPX_OK; }
-  if (!strcmp(name, "epi_split")) { *value = h->epi_split; return GPX_OK; }
-  if (!strcmp(name, "potrf_persist")) { *value = h->potrf_persist; return GPX_OK; }
-  if (!strcmp(name, "build_small")) { *value = h->build_small; return GPX_OK; }
-  if (!strcmp(name, "split_min_blocks")) { *value = h->split_min_blocks; return GPX_OK; }
-  if (!strcmp(name, "host_threads")) { *value = h->host_threads; return GPX_OK; }
-  if (!strcmp(name, "resident")) { *value = h->resident; return GPX_OK; }
-  gpx_set_error(h, std::string("unknown option ") + name);
-  return GPX_ERR_ARG;
+  const int* slot = option_slot(h, name);
+  if (!slot) { gpx_set_error(h, std::string("unknown option ") + name); return GPX_ERR_ARG; }
+  *value = *slot;
+  return GPX_OK;
 }
 
 // ------------------------------------------------------------------ hyper-parameters
 
-// Validate the keyword block against (n rows, d dims) and upload length[d], period[d]
-// (and the per-row noise vector when n_noise == n) to the device.
+// Validate the keyword blocks of `batch` draws against (n rows, d dims) and upload, per draw, length[d], period[d] and
+// the scalars (and the per-row noise vector when n_noise == n) to the device.
 static double kernel_diag_value(int kind, double k_scale);
 
-// Device layout of d_hyp: length[d], period[d], then {k_scale, noise_scalar, k_jitter, prior_diag}
-// (prior_diag = k(x*,x*) + new_noise + jitter, the diagonal of k_new, gpax/gp.py:287).
+// Device layout of d_hyp, per draw (stride s_hyp = 2 d + 4): length[d], period[d], then {k_scale, noise_scalar,
+// k_jitter, prior_diag}  (prior_diag = k(x*,x*) + new_noise + jitter, the diagonal of k_new, gpax/gp.py:287).
+// All draws of a batch share the kernel kind, apply_noise and the form of the noise (scalar or per-row vector).
+static int upload_params_batch(gpx_handle* h, hipStream_t s, const gpx_kernel_params* ps, int batch, int64_t n, int d,
+                               const double** noise_dev, const double* new_noise) {
+  if (!ps || batch < 1) { gpx_set_error(h, "params is NULL"); return GPX_ERR_ARG; }
+  const int64_t sh = 2 * (int64_t)d + 4;
+  std::vector<double> hyp((size_t)(sh * batch));
+  *noise_dev = nullptr;
+  for (int b = 0; b < batch; ++b) {
+    const gpx_kernel_params* p = ps + b;
+    if (p->kind != GPX_RBF && p->kind != GPX_MATERN52 && p->kind != GPX_PERIODIC) {
+      gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
+    }
+    if (!p->k_length || (p->n_length != 1 && p->n_length != d)) {
+      gpx_set_error(h, "k_length must have 1 or d entries"); return GPX_ERR_ARG;
+    }
+    if (p->kind == GPX_PERIODIC && (!p->k_period || (p->n_period != 1 && p->n_period != d))) {
+      // the reference class defines no k_period Parameter (gpax/kernels.py:150-168): it must be passed
+      gpx_set_error(h, "periodic kernel needs k_period with 1 or d entries"); return GPX_ERR_ARG;
+    }
+    if (p->n_noise != 0 && p->n_noise != 1 && p->n_noise != n) {
+      gpx_set_error(h, "k_noise must have 0, 1 or n entries"); return GPX_ERR_ARG;
+    }
+    if (p->n_noise > 0 && !p->k_noise) { gpx_set_error(h, "k_noise is NULL"); return GPX_ERR_ARG; }
+    if (p->kind != ps->kind || p->apply_noise != ps->apply_noise || (p->n_noise > 1) != (ps->n_noise > 1)) {
+      gpx_set_error(h, "the draws of a batch must share kind, apply_noise and the form of k_noise"); return GPX_ERR_ARG;
+    }
+    double* hp = hyp.data() + sh * b;
+    for (int k = 0; k < d; ++k) {
+      hp[k] = p->k_length[p->n_length == 1 ? 0 : k];
+      hp[d + k] = (p->kind == GPX_PERIODIC) ? p->k_period[p->n_period == 1 ? 0 : k] : 1.0;
+    }
+    hp[2 * d + 0] = p->k_scale;
+    hp[2 * d + 1] = (p->n_noise == 1) ? p->k_noise[0] : 0.0;
+    hp[2 * d + 2] = p->k_jitter;
+    hp[2 * d + 3] = kernel_diag_value(p->kind, p->k_scale) + ((new_noise ? new_noise[b] : 0.0) + p->k_jitter);
+  }
+  h->s_hyp = sh;
+  GPX_RET(ensure(h, &h->d_hyp, &h->hyp_cap, sh * batch));
+  GPX_RET(upload_small(h, s, h->d_hyp, hyp.data(), (int64_t)hyp.size()));
+  h->s_noise = 0;
+  if (ps->n_noise > 1) {
+    GPX_RET(ensure(h, &h->d_noise, &h->noise_cap, n * batch));
+    for (int b = 0; b < batch; ++b)
+      GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_noise + n * b, ps[b].k_noise, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+    h->s_noise = n;
+    *noise_dev = h->d_noise;
+  }
+  return GPX_OK;
+}
+
 static int upload_params(gpx_handle* h, hipStream_t s, const gpx_kernel_params* p, int64_t n, int d,
                          const double** noise_dev, double* noise_scalar, double new_noise = 0.0) {
   if (!p) { gpx_set_error(h, "params is NULL"); return GPX_ERR_ARG; }
-  if (p->kind != GPX_RBF && p->kind != GPX_MATERN52 && p->kind != GPX_PERIODIC) {
-    gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
-  }
-  if (!p->k_length || (p->n_length != 1 && p->n_length != d)) {
-    gpx_set_error(h, "k_length must have 1 or d entries"); return GPX_ERR_ARG;
-  }
-  if (p->kind == GPX_PERIODIC && (!p->k_period || (p->n_period != 1 && p->n_period != d))) {
-    // the reference class defines no k_period Parameter (gpax/kernels.py:150-168): it must be passed
-    gpx_set_error(h, "periodic kernel needs k_period with 1 or d entries"); return GPX_ERR_ARG;
-  }
-  if (p->n_noise != 0 && p->n_noise != 1 && p->n_noise != n) {
-    gpx_set_error(h, "k_noise must have 0, 1 or n entries"); return GPX_ERR_ARG;
-  }
-  if (p->n_noise > 0 && !p->k_noise) { gpx_set_error(h, "k_noise is NULL"); return GPX_ERR_ARG; }
-  std::vector<double> hyp(2 * (size_t)d + 4);
-  for (int k = 0; k < d; ++k) {
-    hyp[k] = p->k_length[p->n_length == 1 ? 0 : k];
-    hyp[d + k] = (p->kind == GPX_PERIODIC) ? p->k_period[p->n_period == 1 ? 0 : k] : 1.0;
-  }
-  *noise_dev = nullptr;
+  GPX_RET(upload_params_batch(h, s, p, 1, n, d, noise_dev, &new_noise));
   *noise_scalar = (p->n_noise == 1) ? p->k_noise[0] : 0.0;
-  hyp[2 * d + 0] = p->k_scale;
-  hyp[2 * d + 1] = *noise_scalar;
-  hyp[2 * d + 2] = p->k_jitter;
-  hyp[2 * d + 3] = kernel_diag_value(p->kind, p->k_scale) + (new_noise + p->k_jitter);
-  GPX_RET(ensure(h, &h->d_hyp, &h->hyp_cap, 2 * (int64_t)d + 4));
-  GPX_RET(upload_small(h, s, h->d_hyp, hyp.data(), (int64_t)hyp.size()));
-  if (p->n_noise > 1) {
-    GPX_RET(ensure(h, &h->d_noise, &h->noise_cap, n));
-    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_noise, p->k_noise, (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
-    *noise_dev = h->d_noise;
-  }
   return GPX_OK;
 }
 
@@ -613,635 +523,17 @@ extern "C" int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const dou
   return GPX_OK;
 }
 
-// ------------------------------------------------------------- bordered factorisation
+// ------------------------------------------------------------- bordered factorisation (drivers: schedule.hip)
 
-// Events that only order work between the handle's own streams on one device: a device-scope
-// release is all they need; the default system-scope fence of an event record costs the NEXT kernel of the
-// recording stream ~8 us (measured: 2.24 -> 2.12 ms per N=4096 step with hipEventDisableSystemFence).  Results
-// reach the host through stream-ordered copies, which carry their own fences.
-static unsigned sync_event_flags() {
-  static int mode = -1;
-  if (mode < 0) { const char* e = getenv("GPX_EVENT_MODE"); mode = e ? atoi(e) : 2; }
-  unsigned f = hipEventDisableTiming;
-  if (mode == 1) f |= hipEventReleaseToDevice;
-  if (mode == 2) f |= hipEventDisableSystemFence;
-  return f;
-}
-
-static int ensure_events(gpx_handle* h, size_t nblk) {
-  const unsigned fl = sync_event_flags();
-  if (!h->ev_join) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join, fl));
-  if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
-  if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
-  if (!h->ev_build) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_build, fl));
-  GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, 3 * (int64_t)std::max<size_t>(nblk, 64)));   // flagsU, flagsW, flagsS
-  GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, 2 * (int64_t)h->nb * h->nb));
-  while (h->ev_far.size() < nblk) {
-    hipEvent_t a, b;
-    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, fl));
-    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, fl));
-    h->ev_far.push_back(a);
-    h->ev_w.push_back(b);
-  }
-  while (h->ev_panel.size() < nblk) {
-    hipEvent_t a, b;
-    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, fl));
-    GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, fl));
-    h->ev_panel.push_back(a);
-    h->ev_trail.push_back(b);
-  }
-  return GPX_OK;
-}
-
-static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base);
-
-// Right-looking blocked Cholesky of the (npad x npad) matrix in d_A with `rows - npad`
-// border rows riding along (they are only ever "rows below the panel").  Results in d_L.
-//   step k:  potrf_diag  A_kk -> L_kk, W_k = inv(L_kk)            (one workgroup, LDS resident)   stream P
-//            panel       L_ik = A_ik W_k^T      for all rows below  (MFMA GEMM)                    stream P
-//            near look-ahead  column block k+1 -= panel k           (MFMA GEMM)                    stream P
-//            far look-ahead   column blocks k+2 .. k+D              (MFMA GEMM)                    stream Q
-//            bulk update      column blocks >= k+D+1                (MFMA GEMM)                    stream T
-// P carries the critical path potrf -> panel -> near look-ahead and never waits for the bulk update of
-// the SAME step: with depth D = 2 column k+2 is brought up to date by Q one step early, so the only
-// thing P waits for is Q's short kernel of the previous step, which in turn had a whole step of slack
-// behind the bulk update it depends on.  Every column block has exactly one writer stream at a time
-// (T up to panel c-D-1, then Q, then P), each hand-over ordered by an event: no concurrent
-// read-modify-write of a tile.  D = 1 is the classic single look-ahead (P waits for the previous bulk
-// update); lookahead = 0 runs everything on P.
-// tri_base >= 0: the border rows from `tri_base` on are an identity (gpx_lml_grad: they become
-// U = L^-T); border block j is still all-zero in the panels k < j, so step k only carries rows
-// below tri_base + (k+1)*nb -- the triangular inverse costs N^3/3 flops instead of N^3.
-static int factor_loop(gpx_handle* h, int64_t rows_total, int64_t tri_base = -1) {
-  // one block column (n <= nb): potrf_diag and the border rows' panel solve, nothing to overlap -- one stream,
-  // no events (the multi-stream machinery costs ~20 us of hand-overs on a ~60 us step)
-  // two block columns: one stream as well (measured: 0.136 -> 0.115 ms per N = 256 step; from three on the split schedule wins)
-  if (h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= h->split_min_blocks) return factor_loop_split(h, rows_total, tri_base);
-  const int64_t nb = h->nb, npad = h->npad, ld = h->ld;
-  const int64_t nblk = npad / nb;
-  const bool la = h->lookahead != 0 && nblk >= (h->depth >= 3 ? h->split_min_blocks : 2);
-  const int D = la ? (h->depth >= 2 ? 2 : 1) : 1;
-  hipStream_t P = h->s_main, T = la ? h->s_trail : h->s_main, Q = (la && D >= 2) ? h->s_far : h->s_main;
-  double* A = h->d_A; double* L = h->d_L;
-  std::vector<char> trail_pending((size_t)nblk, 0), far_pending((size_t)nblk, 0);
-
-  auto rows_at = [&](int64_t k) -> int64_t {
-    return tri_base >= 0 ? std::min<int64_t>(rows_total, tri_base + (k + 1) * nb) : rows_total;
-  };
-  auto update = [&](hipStream_t st, int64_t k, int64_t cfirst, int64_t ncolblk, bool small) -> int {
-    // columns [cfirst, cfirst + ncolblk) blocks, rows from block row cfirst down, -= panel k
-    const int64_t rows = rows_at(k);
-    const int64_t c0 = k * nb, rr = cfirst * nb, mr = rows - rr, nc = ncolblk * nb;
-    GemmLaunch t;
-    t.A = L + rr * ld + c0; t.lda = ld;
-    t.B = L + rr * ld + c0; t.ldb = ld;
-    t.C = A + rr * ld + rr; t.ldc = ld;
-    t.M = mr; t.N = nc; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
-    t.lower = 1; t.row_off = rr; t.col_off = rr; t.b_lower_tri = 0; t.small_tile = small ? 1 : 0;
-    const double entries = (double)nc * (nc + 1) / 2.0 + (double)(mr - nc) * nc;   // lower trapezoid, 2*nb flop each
-    prof_begin(h, st, small ? GPX_STAGE_LOOKAHEAD : GPX_STAGE_TRAILING, 2.0 * entries * nb,
-               8.0 * (2.0 * entries + (double)(mr + nc) * nb));
-    int rc = launch_gemm_nt(h, st, t);
-    prof_end(h, st);
-    return rc;
-  };
-
-  for (int64_t k = 0; k < nblk; ++k) {
-    const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
-    prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
-    GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
-                              h->d_info, (int)c0));
-    prof_end(h, P);
-    const int64_t mrows = rows - r0;
-    if (mrows <= 0) continue;
-    GemmLaunch g;
-    g.A = A + r0 * ld + c0; g.lda = ld;
-    g.B = h->d_W + k * nb * nb; g.ldb = nb;
-    g.C = L + r0 * ld + c0; g.ldc = ld;
-    g.M = mrows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
-    g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-    prof_begin(h, P, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
-    GPX_RET(launch_gemm_nt(h, P, g));
-    prof_end(h, P);
-    if (k + 1 >= nblk) continue;
-    const int64_t nfar = std::min<int64_t>(D - 1, nblk - (k + 2));       // column blocks k+2 .. k+D
-    const int64_t nbulk = nblk - (k + 1 + D);                            // column blocks >= k+D+1
-    // near look-ahead (P): column k+1.  Its previous writer was Q (depth 2) or T (depth 1) at step k-1.
-    if (la && k >= 1) {
-      if (D >= 2 && far_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
-      if (D == 1 && trail_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_trail[(size_t)(k - 1)], 0));
-    }
-    GPX_RET(update(P, k, k + 1, 1, true));
-    // The other streams are released only now, after the near look-ahead is queued: the next
-    // diagonal-block kernel is ONE workgroup that needs a whole CU's LDS, and if the bulk kernel were
-    // already resident everywhere it would sit in the dispatcher until that kernel drains (measured:
-    // 37 -> 80 us per panel when the bulk update is released right after the panel solve).
-    if (la && (nfar > 0 || nbulk > 0)) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], P));
-
-    // far look-ahead (Q): columns k+2 .. k+D; column k+D was last written by the bulk update of step k-1
-    if (nfar > 0) {
-      if (la) {
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_panel[(size_t)k], 0));
-        if (k >= 1 && trail_pending[(size_t)(k - 1)]) GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_trail[(size_t)(k - 1)], 0));
-      }
-      GPX_RET(update(Q, k, k + 2, nfar, true));
-      if (la) { GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q)); far_pending[(size_t)k] = 1; }
-    }
-    // bulk update (T): everything right of the look-ahead columns
-    if (nbulk > 0) {
-      if (la) GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
-      GPX_RET(update(T, k, k + 1 + D, nbulk, false));
-      if (la) { GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T)); trail_pending[(size_t)k] = 1; }
-    }
-  }
-  if (la) {   // join: everything on T and Q is done before anything later on P (epilogue, copies)
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
-    if (Q != P) {
-      GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));
-      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join2, 0));
-    }
-  }
-  return GPX_OK;
-}
-
-// Split-panel schedule (depth 3).  The chain stream P carries ONLY what the next diagonal block needs:
-//   P:  potrf(k) -> S = A_{k+1,k} W_k^T (one block row of the panel, 16 workgroups, into scratch)
-//                -> A_{k+1,k+1} -= S S^T (10 workgroups) -> potrf(k+1) ...
-//   Q:  the full panel k (all rows, incl. block row k+1 again: the official L) -> update of columns k+1
-//       (below its diagonal block) and k+2 by panel k
-//   T:  bulk update of the columns >= k+3
-// so the big panel GEMM (which runs 2-3x slower while the bulk kernel owns the CUs) and one
-// cross-stream hand-over leave the critical path: per block column it is potrf + two ~6 us kernels.
-// Hand-overs (each an event): W_k P->Q; panel k Q->T; columns k+1,k+2 Q->P (needed by S of step k+1:
-// a whole diagonal block later); column k+2 T->Q (bulk of step k-1).  One writer per block at a time:
-// block (k+1,k+1) belongs to P at step k (Q's column-k+1 update starts below it).
-static int factor_loop_split(gpx_handle* h, int64_t rows_total, int64_t tri_base) {
-  const int64_t nb = h->nb, npad = h->npad, ld = h->ld, nblk = npad / nb;
-  hipStream_t P = h->s_main, Q = h->s_far, T = h->s_trail;
-  double* A = h->d_A; double* L = h->d_L;
-  auto rows_at = [&](int64_t k) -> int64_t {
-    return tri_base >= 0 ? std::min<int64_t>(rows_total, tri_base + (k + 1) * nb) : rows_total;
-  };
-  // Grouped bulk updates while the factorisation is bulk-bound: T applies the g most recent panels in ONE
-  // K = g nb pass every g-th step, cutting the read-modify-write passes over the trailing matrix g-fold (the bulk
-  // kernel spends about as long on a tile's C traffic as on 128 columns of MFMA work; N = 16384: 42.0 ms with
-  // g = 1, 36.4 with g = 2).  g is chosen per group from the block columns still to go: 4 above `quad_min`,
-  // 2 above `pair_min`, else 1 -- in the chain-bound tail a g-fold kernel would sit one step before its
-  // consumer (N = 4096 with g = 2 throughout: 1.99 -> 2.11 ms).  Invariant after T's step j: every column
-  // >= j+3 is current through panel j; Q brings column k+2 up to date with the panels since then, so a change
-  // of g at a group boundary needs no fix-up.
-  // Q and T fork from P once up front (inside a stream capture a stream must join from the origin stream
-  // first; joining T through an event recorded on Q crashed hipStreamEndCapture on ROCm 7.2)
-  // Resident start of potrf_diag: consecutive diagonal blocks alternate between two chain streams, so
-  // potrf_diag(k+1) is dispatched while block k is still being worked on, owns its CU early and sleeps on the
-  // tile counter that the A -= S S^T kernel of step k publishes (potrf.hip).  Behind a saturating bulk update a
-  // freshly launched potrf_diag waits 20-30 us for a CU to drain (it needs all of its LDS): this removes that
-  // wait from the first ~11 block columns and the launch gap from all of them.
-  const bool resident = h->resident != 0 && !h->in_capture && h->prof_mode != 1 && nblk >= 3;
-  hipStream_t P2 = resident ? h->s_main2 : P;
-  const unsigned n_signal = (unsigned)((nb / 32) * (nb / 32 + 1) / 2);   // lower 32x32 tiles of a diagonal block
-  if (resident && !h->flags_clean) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(3 * nblk) * sizeof(unsigned), P));
-  h->flags_clean = false;
-  // resident == 2: every hand-over of the chain is in-kernel.  The diagonal blocks run on one stream, the two band
-  // kernels on the other; S = A W_k^T is launched while potrf_diag(k) still runs and sleeps on the flag that kernel
-  // raises after its last (write-through) store of W_k -- the ~11 us from potrf_diag's last instruction to the
-  // start of the next kernel of its stream (store drain, kernel-end release, completion signal, launch) shrink to
-  // a flag round trip.
-  const bool chain2 = resident && h->resident >= 2;
-  unsigned* flagsU = h->d_flags;            // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
-  unsigned* flagsW = h->d_flags + nblk;     // [k]: W_k published (S = A W_k^T of step k waits)
-  unsigned* flagsS = h->d_flags + 2 * nblk; // [k]: tiles of S published (fused band kernel: its second phase waits)
-  const bool fuse_band = chain2 && h->fuse_band != 0;
-  const bool persist = chain2 && h->potrf_persist != 0 && h->kinv_U == nullptr && tri_base < 0;   // ONE potrf_diag launch for all blocks
-  GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, P));
-  GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_join, 0));
-  GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_join, 0));
-  if (resident) GPX_HIP_CHECK(h, hipStreamWaitEvent(P2, h->ev_join, 0));
-  // gradient path: K^-1 is accumulated on T while the chain runs (see kinv_update below); T is idle until the
-  // first panel is complete, so clearing the accumulator there costs nothing
-  const bool kinv = h->kinv_U != nullptr;
-  if (kinv) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_kinv, 0, (size_t)(h->kinv_rows * npad) * sizeof(double), T));
-
-  // Host-side hand-shake between the two enqueueing threads: an event may only be waited for after the call
-  // that records it has been ISSUED (a wait on a not-yet-recorded event is a no-op).
-  const bool threaded = h->host_threads >= 2 && !h->prof_mode && !h->in_capture && nblk >= 4;
-  std::unique_ptr<std::atomic<int>[]> w_rec(new std::atomic<int>[(size_t)nblk]), far_rec(new std::atomic<int>[(size_t)nblk]);
-  for (int64_t k = 0; k < nblk; ++k) { w_rec[(size_t)k].store(0); far_rec[(size_t)k].store(0); }
-  std::atomic<int> abort_flag{0};
-  auto await = [&](std::atomic<int>& f) -> bool {   // false: the other side failed
-    if (!threaded) return true;
-    while (f.load(std::memory_order_acquire) == 0)
-      if (abort_flag.load(std::memory_order_acquire)) return false;
-    return true;
-  };
-
-  // completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL stopEvent) except inside a
-  // stream capture and under per-launch profiling, where they are recorded behind the kernel as usual
-  const bool attach = !h->in_capture && h->prof_mode != 1;
-
-  // ---- "diagonal block in the band kernel" (fused band kernel, ungrouped steps).  The column update of step j used to
-  // cover column j+2 from its diagonal block down, behind the wait for the bulk launch that last wrote that column, and
-  // the band kernel of step j+1 waited for all of it -- on alternate block columns of the chain-bound middle of the
-  // factorisation that update (slowed 2x by the bulk launch it shares the CUs with) finished 10-15 us after
-  // potrf_diag(j+1) (profiles/r01_step_timeline_mid.txt).  Now the panel stream's update of column j+2 starts BELOW
-  // the diagonal block, the hand-over event is recorded behind the update of column j+1 alone, and the band kernel
-  // of step j+1 applies panel j to block (j+2,j+2) itself, in a phase 0 that runs while it waits, resident, for
-  // potrf_diag(j+1) -- same tile kernel, same order of the two subtractions, bit-identical result.
-  // dib[k]: the band kernel of step k has that phase 0 (for panel k-1 on block (k+1,k+1)); band_t[k]: the bulk launch
-  // (its step) that last wrote that block and must have finished, or -1.  Both follow from k alone (the grouping is a
-  // function of k), so the chain and the side streams agree without talking.
-  const bool use_dib = fuse_band && h->diag_band != 0 && !kinv;
-  std::vector<char> dib((size_t)nblk + 2, 0);
-  std::vector<int64_t> band_t((size_t)nblk + 2, -1);
-  // lp_flag: the last border panel (chain stream) is ordered behind the panel stream's last column update by a device
-  // counter that update's tiles raise (flagsS[nblk-1], otherwise unused) instead of a stream-level event wait in front
-  // of the last potrf_diag, which kept that kernel from starting resident (+17 us at the tail of every step)
-  bool lp_flag = false;
-  if (chain2 && !kinv) {
-    const int64_t pm = h->pair_min, qm = h->quad_min;
-    auto gsz = [&](int64_t left) -> int64_t { return (qm > 0 && left > qm) ? 4 : ((pm > 0 && left > pm) ? 2 : 1); };
-    int64_t lt = -1, ge = -1, ti = -1, tf = nblk;
-    for (int64_t j = 0; j < nblk; ++j) {
-      if (j > ge) ge = j + gsz(nblk - j) - 1;
-      const int64_t rows = rows_at(j);
-      if (rows - (j + 1) * nb <= 0 || j + 1 >= nblk) continue;
-      int64_t near = 0;
-      if (j == ge && h->near_block) {
-        const int64_t gn = gsz(nblk - (j + 1));
-        if (gn >= 2) near = std::max<int64_t>(0, std::min<int64_t>(gn, nblk - (j + 3)));
-      }
-      const int64_t mr = rows - (j + 2) * nb, ncb = std::min<int64_t>(2, nblk - (j + 1));
-      if (h->lp_flag && j == nblk - 2 && j - lt == 1 && mr > 0 && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) lp_flag = true;
-      if (use_dib && mr > 0 && ncb > 1 && j - lt == 1) {
-        dib[(size_t)(j + 1)] = 1;
-        band_t[(size_t)(j + 1)] = (ti >= 0 && j + 2 >= tf) ? ti : -1;
-      }
-      if (j == ge) {
-        if (nblk - (j + 3 + near) > 0) { ti = j; tf = j + 3 + near; }
-        lt = j;
-      }
-    }
-  }
-  std::vector<hipEvent_t> tev((size_t)nblk, nullptr);   // hand-over event of the bulk launch of step k (set when it is launched)
-  std::unique_ptr<std::atomic<int>[]> trail_rec(new std::atomic<int>[(size_t)nblk]);
-  for (int64_t k = 0; k < nblk; ++k) trail_rec[(size_t)k].store(0);
-
-  // ---- the chain (stream P) at step k: potrf, then the diagonal band
-  auto chain = [&](int64_t k) -> int {
-    // resident == 1: consecutive steps alternate between the two chain streams; resident == 2: potrf_diag on
-    // s_main, the band kernels on P2 (these shadow the outer P)
-    hipStream_t P = chain2 ? h->s_main : ((resident && (k & 1)) ? P2 : h->s_main);
-    hipStream_t PB = chain2 ? P2 : P;   // stream of the two band kernels
-    double* S = h->d_mini + (k & 1) * nb * nb;
-    const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
-    // ev_w[k] = completion of potrf_diag(k): attached to the kernel's own dispatch when possible (no barrier
-    // packet behind it), else recorded right after it -- NOT after the two band kernels (measured 1.91 -> 2.12 ms
-    // per N = 4096 step when the panel stream learns of W_k 12 us later)
-    const bool need_w = rows - r0 > 0;
-    if (need_w && k + 1 >= nblk && !kinv && k >= 1 && !lp_flag) {
-      // The last panel (below) reads the border rows of column k on THIS stream; their last writer is Q's column update
-      // of step k-1.  Nothing else orders the two (potrf_diag(k) only waits for the band kernel of step k-1, which
-      // waited for Q's step k-2): wait for it here, in front of potrf_diag, where it costs nothing -- that update is
-      // normally long finished.  (Without it the race was real at two block columns once the border was built on
-      // the panel stream: one wrong posterior in ~200 runs of the test suite.)
-#ifndef GPX_NO_LASTPANEL_WAIT   // (diagnostic switch: tools/soak.py reproduces the race without the wait)
-      if (!await(far_rec[(size_t)(k - 1)])) return GPX_ERR_HIP;
-      GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_far[(size_t)(k - 1)], 0));
-#endif
-    }
-    if (persist) {
-      // every diagonal block in ONE launch, issued with the first step: the workgroup keeps its CU (potrf.hip)
-      if (k == 0) GPX_RET(launch_potrf_chain(h, P, (int)nb, A, ld, L, ld, h->d_W, h->d_info, (int)nblk, flagsU, n_signal, flagsW));
-    } else {
-      prof_begin(h, P, GPX_STAGE_POTRF_DIAG, (double)nb * nb * nb / 3.0 * 2.0, 3.0 * 8.0 * nb * nb);
-      GPX_RET(launch_potrf_diag(h, P, (int)nb, A + c0 * ld + c0, ld, L + c0 * ld + c0, ld, h->d_W + k * nb * nb,
-                                h->d_info, (int)c0, (need_w && attach) ? h->ev_w[(size_t)k] : nullptr,
-                                (resident && k >= 1) ? flagsU + (k - 1) : nullptr, n_signal,
-                                (chain2 && need_w && k + 1 < nblk) ? flagsW + k : nullptr));
-      prof_end(h, P);
-    }
-    if (!need_w) return GPX_OK;
-    if (k + 1 >= nblk && !kinv) {
-      // the last panel is the border rows only and nothing follows it but the epilogue: it runs on the chain stream,
-      // behind potrf_diag, instead of hopping to the panel stream and back (two ~8 us event hand-overs)
-      GemmLaunch g;
-      g.A = A + r0 * ld + c0; g.lda = ld;
-      g.B = h->d_W + k * nb * nb; g.ldb = nb;
-      g.C = L + r0 * ld + c0; g.ldc = ld;
-      g.M = rows - r0; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
-      g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-      if (lp_flag && k >= 1) {   // its input rows were last written by the panel stream's column update of step k-1: wait for that update's tiles
-        g.wait_flag = flagsS + k; g.wait_count = (unsigned)((nb / 32) * ((rows - r0) / 32)); g.wait_info = h->d_info;
-      }
-      prof_begin(h, P, GPX_STAGE_TRSM_PANEL, (double)g.M * nb * nb, 8.0 * (2.0 * g.M * nb + nb * nb));
-      GPX_RET(launch_gemm_nt(h, P, g));
-      prof_end(h, P);
-      return GPX_OK;   // (the gradient path keeps its last panel on Q: the K^-1 update behind it belongs to T's sequence)
-    }
-    if (!attach && !persist) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], P));
-    w_rec[(size_t)k].store(1, std::memory_order_release);
-    if (k + 1 >= nblk) return GPX_OK;
-    if (k >= 1) {   // columns k, k+1 were brought up to date by Q at step k-1
-      if (!await(far_rec[(size_t)(k - 1)])) return GPX_ERR_HIP;
-      GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_far[(size_t)(k - 1)], 0));
-    }
-    GemmLaunch g;
-    g.A = A + r0 * ld + c0; g.lda = ld;
-    g.B = h->d_W + k * nb * nb; g.ldb = nb;
-    g.C = S; g.ldc = nb;
-    g.M = nb; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
-    g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-    if (chain2) { g.wait_flag = flagsW + k; g.wait_count = 1; g.wait_info = h->d_info; }   // W_k arrives in-kernel from potrf_diag(k)
-    GemmLaunch u;
-    u.A = S; u.lda = nb; u.B = S; u.ldb = nb;
-    u.C = A + r0 * ld + r0; u.ldc = ld;
-    u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
-    u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
-    if (resident) u.signal = flagsU + k;   // potrf_diag(k+1) is already resident and polls this counter
-    if (fuse_band) {   // both band kernels in one launch: S's tiles are handed over through flagsS[k]
-      g.signal = flagsS + k;
-      u.wait_flag = flagsS + k; u.wait_count = (unsigned)((nb / 32) * (nb / 32)); u.wait_info = h->d_info;
-      GemmLaunch z;   // phase 0: block (k+1,k+1) -= L_{k+1,k-1} L_{k+1,k-1}^T (panel k-1), see dib[] above
-      const bool phase0 = dib[(size_t)k] != 0;
-      if (phase0) {
-        if (band_t[(size_t)k] >= 0) {   // the bulk launch that last wrote the block
-          if (!await(trail_rec[(size_t)band_t[(size_t)k]])) return GPX_ERR_HIP;
-          GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)band_t[(size_t)k]], 0));
-        }
-        z.A = L + r0 * ld + (k - 1) * nb; z.lda = ld;
-        z.B = z.A; z.ldb = ld;
-        z.C = A + r0 * ld + r0; z.ldc = ld;
-        z.M = nb; z.N = nb; z.K = nb; z.alpha = -1.0; z.beta = 1.0;
-        z.lower = 1; z.row_off = 0; z.col_off = 0; z.b_lower_tri = 0; z.small_tile = 1;
-      }
-      prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (phase0 ? 3.0 : 2.0) * (double)nb * nb * nb, 8.0 * 6.0 * nb * nb);
-      GPX_RET(launch_chain_band(h, PB, phase0 ? &z : nullptr, g, u));
-      prof_end(h, PB);
-      return GPX_OK;
-    }
-    prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
-    GPX_RET(launch_gemm_nt(h, PB, g));
-    prof_end(h, PB);
-    prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, (double)nb * nb * nb, 8.0 * 3.0 * nb * nb);
-    GPX_RET(launch_gemm_nt(h, PB, u));
-    prof_end(h, PB);
-    return GPX_OK;
-  };
-
-  // ---- the side streams at step k: Q (whole panel, columns k+1 and k+2), T (bulk)
-  // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
-  // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
-  const int64_t pair_min = kinv ? std::min<int64_t>(h->pair_min, 8) : h->pair_min, quad_min = h->quad_min;
-  int64_t last_t = -1;        // last group end (panels <= last_t are in every column >= last_t+3: by Q's near block and T's bulk launch)
-  int64_t group_end = -1;     // the step at which T acts next
-  int64_t q_waited_t = -1;    // the T launch (its step) Q has already waited for
-  int64_t t_idx = -1;         // step of the most recent bulk launch on T (its hand-over event is ev_trail[t_idx])
-  int64_t t_from = nblk;      // first block column that launch wrote: Q waits for it only before touching a column >= t_from
-  auto group_size = [&](int64_t left) -> int64_t {
-    return (quad_min > 0 && left > quad_min) ? 4 : ((pair_min > 0 && left > pair_min) ? 2 : 1);
-  };
-  int64_t kinv_last = -1;     // last panel folded into K^-1 (gradient path)
-  static int kinv_group_env = -1;
-  if (kinv_group_env < 0) { const char* e = getenv("GPX_KINV_GROUP"); kinv_group_env = e ? atoi(e) : 2; }
-  const int64_t kinv_group = std::max(kinv_group_env, 1);
-  std::vector<char> t_pending((size_t)nblk, 0);
-  auto side = [&](int64_t k) -> int {
-    if (k > group_end) {
-      group_end = k + group_size(nblk - k) - 1;
-    }
-    const int64_t c0 = k * nb, r0 = c0 + nb, rows = rows_at(k);
-    const int64_t mrows = rows - r0;
-    if (mrows <= 0) return GPX_OK;
-    if (k + 1 >= nblk && !kinv) return GPX_OK;   // the last panel (border rows only) is launched by the chain itself
-    // Grouped phases: the bulk launch at a group end leaves the NEXT group's columns (the "near block", as many block
-    // columns as that group has panels) to Q, which applies the same panels to them in one K = g nb launch of its own.
-    // The chain of the next group then depends on that short launch only and runs WHILE the bulk launch does; with
-    // the bulk launch covering everything from column k+3 the chain stalled at the first step of every group until
-    // the bulk launch had finished and the bulk stream then idled for the 2-4 chain steps that produce its next
-    // panels (N = 16384: ~270 us of every ~2.3 ms).
-    int64_t near_cols = 0;
-    if (k == group_end && h->near_block && !kinv) {
-      const int64_t g_next = group_size(nblk - (k + 1));
-      if (g_next >= 2) near_cols = std::max<int64_t>(0, std::min<int64_t>(g_next, nblk - (k + 3)));
-    }
-    if (!await(w_rec[(size_t)k])) return GPX_ERR_HIP;
-    // (Starting the panel kernel resident too -- it would sleep on potrf_diag's flag instead of waiting ~8 us for the
-    // cross-stream event -- crowds the bulk update with sleeping workgroups: 1.76 -> 1.81 ms, not used.)
-    if (persist) GPX_RET(launch_flag_relay(h, Q, flagsW + k, 1u, h->d_info));   // W_k: the one potrf_diag launch raises flagsW[k]
-    else GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
-    {
-      GemmLaunch g;
-      g.A = A + r0 * ld + c0; g.lda = ld;
-      g.B = h->d_W + k * nb * nb; g.ldb = nb;
-      g.C = L + r0 * ld + c0; g.ldc = ld;
-      g.M = mrows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
-      g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-      // T gets its own event on the panel: the bulk update must not wait for the column kernels below (with one
-      // shared event after them the N = 4096 step went from 1.90 to 2.17 ms: every bulk update starts late)
-      const bool t_needs = (k + 1 < nblk && k == group_end && nblk - (k + 3 + near_cols) > 0) || (kinv && (k == group_end || k + 1 >= nblk));
-      if (t_needs && attach) g.stop_event = h->ev_panel[(size_t)k];
-      prof_begin(h, Q, GPX_STAGE_TRSM_PANEL, (double)mrows * nb * nb, 8.0 * (2.0 * mrows * nb + nb * nb));
-      GPX_RET(launch_gemm_nt(h, Q, g));
-      prof_end(h, Q);
-      if (t_needs && !attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_panel[(size_t)k], Q));
-      // every block column but the last is final now (V^T, z and the diagonal of L): their share of the epilogue's
-      // reductions runs here, on the panel stream, beside the last potrf_diag instead of behind the last panel
-      if (h->epi && k == nblk - 2 && nblk >= 3 && h->d_epart) {
-        GPX_RET(launch_epilogue_partial(h, Q, *h->epi, (nblk - 1) * nb, h->d_epart));
-        h->epi_split_col = (nblk - 1) * nb;
-      }
-    }
-    // K^-1 += U_{:,j} U_{:,j}^T for the panels j = last_t+1 .. k that are complete now (gradient path): rank-(npan nb)
-    // update of the leading (k+1) nb square, lower tiles, on T.  Small while the bulk updates are big and growing as
-    // they shrink, it fills the chain-bound second half of the factorisation with the N^3/3 flops that used to
-    // follow it as one U U^T product (2.9 -> 2.2 ms per gradient call at N = 4096).
-    auto kinv_update = [&]() -> int {
-      const int64_t kfirst = kinv_last + 1, npan = k - kinv_last;
-      kinv_last = k;
-      const int64_t msq = std::min<int64_t>(h->kinv_rows, (k + 1) * nb);
-      GemmLaunch t;
-      t.A = h->kinv_U + kfirst * nb; t.lda = ld;
-      t.B = h->kinv_U + kfirst * nb; t.ldb = ld;
-      t.C = h->d_kinv; t.ldc = npad;
-      t.M = msq; t.N = msq; t.K = npan * nb; t.alpha = 1.0; t.beta = 1.0;
-      t.lower = 1; t.row_off = 0; t.col_off = 0; t.b_lower_tri = 0; t.small_tile = 0;
-      const double entries = (double)msq * (msq + 1) / 2.0;
-      prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + 2.0 * (double)msq * t.K));
-      int rc = launch_gemm_nt(h, T, t);
-      prof_end(h, T);
-      return rc;
-    };
-    if (k + 1 >= nblk) {   // border rows only: nothing left to update
-      if (kinv) {
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
-        GPX_RET(kinv_update());
-      }
-      return GPX_OK;
-    }
-
-    // Q keeps two columns current ahead of the chain: column k+1 (below its diagonal block) gets panel k, column
-    // k+2 every panel since T's last step; rows from block row k+2 down.  (A third window column, which takes T
-    // off everything P waits for, was tried with and without grouped updates: 1.94-2.02 vs 1.88 ms at N = 4096.)
-    const int64_t rr = (k + 2) * nb, mr = rows - rr;
-    bool far_attached = false;
-    auto col_update = [&](int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last, int64_t skip_blocks = 0) -> int {
-      GemmLaunch t;   // columns [cfirst, cfirst+ncol) blocks, rows >= rr (+ skip_blocks block rows), -= panels [kfirst, kfirst+npan)
-      const int64_t rr = (k + 2 + skip_blocks) * nb, mr = rows - rr;
-      if (mr <= 0) return GPX_OK;
-      if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
-      t.A = L + rr * ld + kfirst * nb; t.lda = ld;
-      t.B = L + cfirst * nb * ld + kfirst * nb; t.ldb = ld;
-      t.C = A + rr * ld + cfirst * nb; t.ldc = ld;
-      t.M = mr; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-      t.lower = 1; t.row_off = rr; t.col_off = cfirst * nb; t.b_lower_tri = 0;
-      if (lp_flag && k == nblk - 2 && cfirst == nblk - 1) t.signal = flagsS + (nblk - 1);   // the last border panel waits for these tiles (chain stream)
-      // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
-      // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency
-      t.small_tile = (h->la_rows > 0 && mr >= h->la_rows) ? 0 : 1;
-      t.role = 1;
-      double entries = 0.0;
-      for (int64_t c = cfirst; c < cfirst + ncol; ++c)
-        entries += (c * nb >= rr) ? (double)nb * (nb + 1) / 2.0 + (double)(mr - nb) * nb : (double)mr * nb;
-      prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(mr + ncol * nb) * t.K));
-      int rc = launch_gemm_nt(h, Q, t);
-      prof_end(h, Q);
-      return rc;
-    };
-    const int64_t ncb = std::min<int64_t>(2, nblk - (k + 1));
-    if (mr > 0) {
-      auto wait_for_t = [&]() -> int {   // column k+2 was last written by the bulk launch of step t_idx -- if it lies in its range
-        if (t_idx >= 0 && k + 2 >= t_from && t_idx != q_waited_t && t_pending[(size_t)t_idx]) {
-          GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, tev[(size_t)t_idx], 0));
-          q_waited_t = t_idx;
-        }
-        return GPX_OK;
-      };
-      const int64_t npan2 = k - last_t;   // panels column k+2 still lacks: last_t+1 .. k
-      // While the factorisation is bulk-bound the two columns go separately: column k+1 (whose last bulk update
-      // Q waited for a step ago) needs no bulk update to finish, only column k+2 does.  As one two-column kernel
-      // behind the wait, the update -- slowed 3-4x by the bulk kernel it shares the CUs with -- and the next panel
-      // behind it took longer than one bulk update, and the bulk stream idled ~18 us per step at N = 4096.
-      const bool split = ncb > 1 && (npan2 > 1 || (h->col_split > 0 && nblk - (k + 3) >= h->col_split));
-      if (dib[(size_t)(k + 1)]) {
-        // column k+1 alone carries the hand-over to the chain; column k+2 from BELOW its diagonal block, behind the
-        // wait for the bulk launch (the band kernel of step k+1 applies panel k to that block itself)
-        GPX_RET(col_update(k + 1, 1, k, 1, true));
-        if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
-        far_attached = true;   // recorded (or attached) already: not again behind the second column
-        far_rec[(size_t)k].store(1, std::memory_order_release);
-        GPX_RET(wait_for_t());
-        GPX_RET(col_update(k + 2, 1, k, 1, false, 1));
-      } else if (split) {
-        GPX_RET(col_update(k + 1, 1, k, 1, false));
-        GPX_RET(wait_for_t());
-        GPX_RET(col_update(k + 2, 1, last_t + 1, npan2, true));
-      } else {
-        GPX_RET(wait_for_t());
-        GPX_RET(col_update(k + 1, ncb, k, 1, true));
-      }
-    }
-    if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
-    far_rec[(size_t)k].store(1, std::memory_order_release);
-
-    // Q: the near block (columns k+3 .. k+2+near_cols, panels last_t+1 .. k), behind the event the chain waits for
-    if (near_cols > 0) {
-      if (t_idx >= 0 && t_idx != q_waited_t && t_pending[(size_t)t_idx]) {   // those columns were last written by the previous bulk launch
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, tev[(size_t)t_idx], 0));
-        q_waited_t = t_idx;
-      }
-      const int64_t kfirst = last_t + 1, npan = k - last_t;
-      const int64_t br = (k + 3) * nb, bm = rows - br, nc = near_cols * nb;
-      GemmLaunch t;
-      t.A = L + br * ld + kfirst * nb; t.lda = ld;
-      t.B = L + br * ld + kfirst * nb; t.ldb = ld;
-      t.C = A + br * ld + br; t.ldc = ld;
-      t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-      t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0; t.role = 1;
-      const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
-      prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
-      GPX_RET(launch_gemm_nt(h, Q, t));
-      prof_end(h, Q);
-    }
-    // T: bulk, columns >= k+3 (+ the near block), panels last_t+1 .. k in one pass
-    const int64_t nbulk = nblk - (k + 3 + near_cols);
-    if (k == group_end) {
-      if (nbulk > 0) {
-        GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
-        const int64_t kfirst = last_t + 1, npan = k - last_t;
-        const int64_t cf = k + 3 + near_cols, br = cf * nb, bm = rows - br, nc = nbulk * nb;
-        GemmLaunch t;
-        t.A = L + br * ld + kfirst * nb; t.lda = ld;
-        t.B = L + br * ld + kfirst * nb; t.ldb = ld;
-        t.C = A + br * ld + br; t.ldc = ld;
-        t.M = bm; t.N = nc; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
-        t.lower = 1; t.row_off = br; t.col_off = br; t.b_lower_tri = 0; t.small_tile = 0;
-        const double entries = (double)nc * (nc + 1) / 2.0 + (double)(bm - nc) * nc;
-        // profiled: the kernel's own dispatch timestamps (what rocprofv3 reports), the hand-over event recorded behind it
-        const bool timed = prof_pair(h, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + (double)(bm + nc) * t.K),
-                                     &t.start_event, &t.stop_event);
-        // timed (profile mode 3): the timing stop event, attached to the kernel's own dispatch, IS the hand-over event -- a
-        // second record behind the launch delayed every consumer of the bulk update and stretched the measured step by 10 %
-        if (attach && !timed) t.stop_event = h->ev_trail[(size_t)k];
-        tev[(size_t)k] = (attach && timed) ? t.stop_event : h->ev_trail[(size_t)k];
-        GPX_RET(launch_gemm_nt(h, T, t));
-        if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_trail[(size_t)k], T));
-        t_pending[(size_t)k] = 1;
-        trail_rec[(size_t)k].store(1, std::memory_order_release);
-        t_idx = k; t_from = cf;
-      }
-      // behind the bulk update (Q's next column update waits for that one, not for this), two panels at a time:
-      // nothing waits for K^-1 before the end and K = 2 nb passes run at 48 instead of 40 TFLOP/s (groups of 4 or 8
-      // leave a long last pass exposed behind the chain: 2.58 / 2.68 / 2.85 ms per call at N = 4096)
-      if (kinv && (k - kinv_last >= kinv_group || k + 2 >= nblk)) {
-        if (nbulk <= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
-        GPX_RET(kinv_update());
-      }
-      last_t = k;
-    }
-    return GPX_OK;
-  };
-
-  int rc = GPX_OK;
-  if (threaded) {
-    int side_rc = GPX_OK;
-    h->worker.start(h->device);
-    h->worker.post([&]() {
-      for (int64_t k = 0; k < nblk && side_rc == GPX_OK; ++k) side_rc = side(k);
-      if (side_rc != GPX_OK) abort_flag.store(1, std::memory_order_release);
-    });
-    for (int64_t k = 0; k < nblk && rc == GPX_OK; ++k) rc = chain(k);
-    if (rc != GPX_OK) abort_flag.store(1, std::memory_order_release);
-    h->worker.wait();
-    if (rc == GPX_OK) rc = side_rc;
-  } else {
-    for (int64_t k = 0; k < nblk && rc == GPX_OK; ++k) {
-      rc = chain(k);
-      if (rc == GPX_OK) rc = side(k);
-    }
-  }
-  GPX_RET(rc);
-  if (resident) {
-    GPX_HIP_CHECK(h, hipEventRecord(h->ev_chain2, P2));
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_chain2, 0));
-  }
-  GPX_HIP_CHECK(h, hipEventRecord(h->ev_join, T));
-  GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join, 0));
-  GPX_HIP_CHECK(h, hipEventRecord(h->ev_join2, Q));
-  GPX_HIP_CHECK(h, hipStreamWaitEvent(P, h->ev_join2, 0));
-  return GPX_OK;
-}
-
-// ---- the bordered factorisation, in three parts so that the enqueue part can be captured
-// into a hipGraph: (1) sizes + allocations, (2) hyper-parameter upload, (3) pure enqueue.
+// ---- the bordered factorisation in three parts: (1) sizes + allocations, (2) hyper-parameter upload, (3) pure enqueue.
 struct FactorPlan {
   int kind; int apply_noise;
   int64_t m_rows; bool with_r;
-  const double* noise_dev;   // per-row noise vector on the device, or nullptr
+  const double* noise_dev;   // per-row noise vector(s) on the device, or nullptr
   bool want_k;               // full (not lower-only) K build for a K_out copy
 };
 
-static int factor_prepare(gpx_handle* h, int64_t m_rows, bool with_r) {
+static int factor_prepare(gpx_handle* h, int64_t m_rows, bool with_r, int batch = 1) {
   if (h->n <= 0 || !h->d_x) { gpx_set_error(h, "no training inputs: call gpx_set_train first"); return GPX_ERR_STATE; }
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
   const int64_t n = h->n, nb = h->nb;
@@ -1249,26 +541,30 @@ static int factor_prepare(gpx_handle* h, int64_t m_rows, bool with_r) {
   const int64_t E = m_rows + (with_r ? 1 : 0);
   const int64_t epad = E > 0 ? round_up(E, 64) : 0;
   const int64_t rows = npad + epad, ld = npad;
-  GPX_RET(ensure(h, &h->d_A, &h->a_cap, rows * ld));
-  GPX_RET(ensure(h, &h->d_L, &h->l_cap, rows * ld));
-  GPX_RET(ensure(h, &h->d_W, &h->w_cap, npad * nb));
-  GPX_RET(ensure(h, &h->d_z, &h->z_cap, npad));
-  GPX_RET(ensure_out(h, 2 * std::max<int64_t>(m_rows, 1)));
-  GPX_RET(ensure_events(h, (size_t)(npad / nb)));
+  h->batch = batch;
+  h->s_mat = rows * ld; h->s_w = npad * nb; h->s_z = npad;
+  GPX_RET(ensure(h, &h->d_A, &h->a_cap, h->s_mat * batch));
+  GPX_RET(ensure(h, &h->d_L, &h->l_cap, h->s_mat * batch));
+  GPX_RET(ensure(h, &h->d_W, &h->w_cap, h->s_w * batch));
+  GPX_RET(ensure(h, &h->d_z, &h->z_cap, h->s_z * batch));
+  GPX_RET(ensure_out(h, 2 * std::max<int64_t>(m_rows, 1), batch));
+  GPX_RET(ensure_events(h, (size_t)(npad / nb), (int)nb, batch));
   h->have_factor = false; h->have_z = false;
   h->npad = npad; h->epad = epad; h->ld = ld;
   return GPX_OK;
 }
 
-// Build [K ; k_cross ; r] in d_A, factorise, leave [L ; V^T ; z^T] in d_L.  Enqueue only
-// (kernel launches, memsets, device-to-device copies, stream events): capturable.
+// Build [K ; k_cross ; r] in d_A (for every draw of the batch), factorise, leave [L ; V^T ; z^T] in d_L.  Enqueue only
+// (kernel launches, memsets, device-to-device copies, stream events).
 static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   const int64_t n = h->n, npad = h->npad, ld = h->ld; const int d = h->d;
   const int64_t m_rows = fp.m_rows;
   const int64_t E = m_rows + (fp.with_r ? 1 : 0);
   const int64_t rows = npad + h->epad;
+  const int B = h->batch;
   hipStream_t s = h->s_main;
   const double* dev_scalars = h->d_hyp + 2 * d;
+  const int64_t s_info = 2 * h->s_out;
 
   // K (diagonal rule on for k_train: gpax/gp.py:293 calls f(x, x, k_noise, k_jitter))
   GramLaunch g;
@@ -1276,11 +572,12 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   g.x1 = h->d_x; g.x2 = h->d_x; g.n1 = n; g.n2 = n; g.out = h->d_A; g.ld = ld;
   g.lower_only = fp.want_k ? 0 : 1; g.diag_rule = fp.apply_noise ? 1 : 0;
   g.noise = fp.noise_dev; g.noise_scalar = 0.0; g.jitter = 0.0;
+  g.batch = B; g.s_out = h->s_mat; g.s_hyp = h->s_hyp; g.s_noise = h->s_noise; g.s_info = s_info; g.s_flags = h->s_flags;
   auto gram_cost = [&](int64_t c0, int64_t c1, double* fl, double* by) {   // lower tiles of the column slice [c0, c1)
     double entries = 0.0;
     for (int64_t c = c0 / 64; c * 64 < c1; ++c) entries += (double)((n + 63) / 64 - c) * 4096.0;
     if (fp.want_k) entries = (double)n * (double)(c1 - c0);
-    *fl = gram_flops_per_entry(fp.kind, d) * entries; *by = 8.0 * entries + 8.0 * (double)(n + c1 - c0) * d;
+    *fl = B * gram_flops_per_entry(fp.kind, d) * entries; *by = B * (8.0 * entries + 8.0 * (double)(n + c1 - c0) * d);
   };
   auto cross_gram = [&](hipStream_t st) -> int {
     if (m_rows <= 0) return GPX_OK;
@@ -1288,21 +585,24 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     c.x1 = h->d_xnew; c.n1 = m_rows; c.out = h->d_A + npad * ld; c.lower_only = 0; c.diag_rule = 0;
     c.noise = nullptr; c.zero_info = nullptr; c.zero_flags = nullptr; c.col0 = 0; c.x2 = h->d_x; c.n2 = n;
     c.start_event = c.stop_event = nullptr;
-    prof_begin(h, st, GPX_STAGE_GRAM_CROSS, gram_flops_per_entry(fp.kind, d) * m_rows * n,
-               8.0 * m_rows * n + 8.0 * (m_rows + n) * d);
+    prof_begin(h, st, GPX_STAGE_GRAM_CROSS, B * gram_flops_per_entry(fp.kind, d) * m_rows * n,
+               B * (8.0 * m_rows * n + 8.0 * (m_rows + n) * d));
     int rc = launch_gram(h, st, c);
     prof_end(h, st);
     return rc;
   };
+  const bool split = h->lookahead != 0 && npad / h->nb >= h->split_min_blocks;   // factor_loop's dispatch
   double fl, by;
-  if (h->build_small && npad <= 256 && npad / h->nb < h->split_min_blocks && !fp.want_k && !K_out) {
-    // one block column: the whole bordered matrix in ONE launch (gram.hip) -- at these sizes the step is launch latency
+  if (npad <= 256 && !split && !fp.want_k && !K_out) {
+    // one or two block columns on one stream: the whole bordered matrix in ONE launch (gram.hip) -- at these sizes the
+    // step is launch latency
     gram_cost(0, n, &fl, &by);
     prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
     GPX_RET(launch_build_small(h, s, fp.kind, h->d_x, h->d_xnew, h->d_hyp, dev_scalars, fp.noise_dev, h->d_r, h->d_A, ld, n, npad,
-                               m_rows, fp.with_r ? npad + m_rows : -1, rows, d, fp.apply_noise ? 1 : 0, h->d_info, nullptr, 0));
+                               m_rows, fp.with_r ? npad + m_rows : -1, rows, d, fp.apply_noise ? 1 : 0, h->d_info, nullptr, 0,
+                               -1, nullptr, nullptr, B, h->s_mat, h->s_hyp, h->s_noise, h->s_r, s_info));
     prof_end(h, s);
-    const int lrc = factor_loop(h, rows);
+    const int lrc = factor_loop(h, primary_mats(h, rows));
     h->flags_clean = false;
     GPX_RET(lrc);
     return GPX_OK;
@@ -1319,25 +619,25 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
                                       (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
   }
-  GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
+  GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows, B, h->s_mat));
   // The border (k_cross rows, the r row, the zero rows) is not read by the chain before the very last panel: with the
   // split-panel schedule it is built on the panel stream, whose first kernel (the panel of block column 0) is its
   // first reader, while the chain stream goes straight from K to potrf_diag(0) -- ~30 us off the head of the step.
   // (Building most of K itself on the bulk stream while the chain already factorises was tried: no gain at N = 4096,
   // 1.907 vs 1.905 ms -- the first steps are bound by that stream.)
-  const bool border_on_q = h->border_side && h->lookahead != 0 && h->depth >= 3 && npad / h->nb >= h->split_min_blocks && !h->in_capture && h->prof_mode != 1;
   hipStream_t sb = s;
-  if (border_on_q) {
+  if (split && h->prof_mode != 1) {
     sb = h->s_far;
     GPX_HIP_CHECK(h, hipEventRecord(h->ev_build, s));
     GPX_HIP_CHECK(h, hipStreamWaitEvent(sb, h->ev_build, 0));
   }
   GPX_RET(cross_gram(sb));
   // the r row and the unused (zero) border rows in one launch
-  GPX_RET(launch_border_rows(h, sb, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr));
+  GPX_RET(launch_border_rows(h, sb, h->d_A, ld, npad, n, fp.with_r ? npad + m_rows : -1, h->d_r, npad + E, rows, nullptr, B,
+                             h->s_mat, h->s_r));
 
-  const int lrc = factor_loop(h, rows);
-  h->flags_clean = false;   // consumed by the split-panel loop, or unused by the others: never carried into another call
+  const int lrc = factor_loop(h, primary_mats(h, rows));
+  h->flags_clean = false;   // consumed by the split-panel loop, or unused by the single-stream one: never carried into another call
   GPX_RET(lrc);
 
   return GPX_OK;   // z = L^-1 r (row npad + m_rows of d_L) is copied to d_z by the fused epilogue of the caller
@@ -1366,15 +666,24 @@ static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_ro
 }
 
 // info == -7: a resident kernel gave up waiting for its producer (potrf.hip / gemm.hip: bounded spin).  That only
-// happens when something serialises the dispatches (a profiler collecting counters, a debugger): switch the handle
-// to kernel-boundary hand-overs and tell the caller to repeat the call.
+// happens when something keeps the chain's kernels from running concurrently (a profiler collecting counters, a
+// debugger, other work holding the CUs): the handle switches to kernel-boundary hand-overs for good and the call is
+// repeated -- by the synchronous entry points themselves (with_retry), by the caller of the asynchronous pair
+// (gpx_fetch_results returns GPX_ERR_RETRY; gpax_amd._lib.Core re-issues the step).
 static int check_handover(gpx_handle* h, int info) {
   if (info != -7) return GPX_OK;
   h->resident = 0;
   h->have_factor = false; h->have_z = false;
   gpx_set_error(h, "in-kernel hand-over timed out (are kernel dispatches being serialised, e.g. by counter collection?); "
                    "switched to kernel-boundary hand-overs (option \"resident\" = 0): repeat the call");
-  return GPX_ERR_STATE;
+  return GPX_ERR_RETRY;
+}
+
+template <typename F>
+static int with_retry(F&& call) {
+  int rc = call();
+  if (rc == GPX_ERR_RETRY) rc = call();   // "resident" is 0 now: no in-kernel wait is left to time out
+  return rc;
 }
 
 static int read_info(gpx_handle* h, int* info) {
@@ -1384,8 +693,7 @@ static int read_info(gpx_handle* h, int* info) {
   return check_handover(h, *info);
 }
 
-extern "C" int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double* K_out, double* L_out) {
-  if (!h) return GPX_ERR_ARG;
+static int fit_factor_once(gpx_handle* h, const gpx_kernel_params* p, double* K_out, double* L_out) {
   GPX_RET(factor_common(h, p, 0, false, K_out));
   const int64_t n = h->n;
   if (L_out) {
@@ -1399,6 +707,11 @@ extern "C" int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double*
       for (int64_t j = i + 1; j < n; ++j) L_out[i * n + j] = 0.0;
   }
   return info;
+}
+
+extern "C" int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double* K_out, double* L_out) {
+  if (!h) return GPX_ERR_ARG;
+  return with_retry([&] { return fit_factor_once(h, p, K_out, L_out); });
 }
 
 // ------------------------------------------------------- solves against the cached factor
@@ -1478,9 +791,8 @@ extern "C" int gpx_log_marginal(gpx_handle* h, const double* y_minus_m, double* 
 // block by block, factor_loop's tri_base), then alpha = U z, K^-1 = U U^T (lower tiles, dead-K skipped)
 // and ONE pass over K^-1 that recomputes dK/dtheta from x (grad.hip).  ~N^3 flops in total against
 // N^3/3 for the factorisation alone -- versus 2*p+1 factorisations for central differences.
-extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const double* y_minus_m, double* logp,
-                            double* grad_out, double* alpha_out) {
-  if (!h) return GPX_ERR_ARG;
+static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double* y_minus_m, double* logp,
+                         double* grad_out, double* alpha_out) {
   if (!p || !y_minus_m) { gpx_set_error(h, "gpx_lml_grad: params / y_minus_m is NULL"); return GPX_ERR_ARG; }
   if (h->n <= 0 || !h->d_x) { gpx_set_error(h, "no training inputs: call gpx_set_train first"); return GPX_ERR_STATE; }
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
@@ -1492,6 +804,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   hipStream_t s = h->s_main;
 
   h->have_factor = false; h->have_z = false;
+  h->batch = 1; h->s_mat = rows * ld; h->s_w = npad * nb; h->s_z = npad; h->s_r = 0; h->s_mnew = 0;
   GPX_RET(ensure(h, &h->d_A, &h->a_cap, rows * ld));
   GPX_RET(ensure(h, &h->d_L, &h->l_cap, rows * ld));
   GPX_RET(ensure(h, &h->d_W, &h->w_cap, npad * nb));
@@ -1504,13 +817,14 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   const int DCH = grad_chunk_dims(), NPVv = grad_partials_per_chunk();
   const int nchunk = per_dim ? (d + DCH - 1) / DCH : 1;
   GPX_RET(ensure_out(h, npad + (int64_t)nchunk * NPVv));
-  GPX_RET(ensure_events(h, (size_t)(npad / nb)));
+  GPX_RET(ensure_events(h, (size_t)(npad / nb), (int)nb, 1));
   h->npad = npad; h->epad = epad; h->ld = ld;
 
   const double* noise_dev; double noise_scalar;
   GPX_RET(upload_params(h, s, p, n, d, &noise_dev, &noise_scalar));
   // small problems: the one-launch build below reads r straight from a pinned slot (and writes d_r on the way): no upload in the stream
-  const bool r_in_place = h->build_small && npad <= 256 && npad / nb < h->split_min_blocks;
+  const bool split = h->lookahead != 0 && npad / nb >= h->split_min_blocks;   // factor_loop's dispatch
+  const bool r_in_place = npad <= 256 && !split;
   const double* r_src = h->d_r; int r_slot = -1;
   if (r_in_place) GPX_RET(stage_small(h, y_minus_m, n, &r_src, &r_slot));
   else if (n <= 65536) GPX_RET(upload_small(h, s, h->d_r, y_minus_m, n));   // through the pinned ring: truly asynchronous
@@ -1518,7 +832,7 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
   h->have_r = true;
 
   // ---- [K ; r ; I] in d_A
-  const bool one_launch = h->build_small && npad <= 256 && npad / nb < h->split_min_blocks;   // one stream, small: one launch builds everything below (gram.hip)
+  const bool one_launch = r_in_place;   // one stream, small: one launch builds everything below (gram.hip)
   if (one_launch) {
     const double T = (double)((n + 63) / 64);
     const double entries = T * (T + 1) / 2.0 * 4096.0;
@@ -1555,11 +869,11 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
 
   const double* zrow = h->d_L + npad * ld;
   const double* U = h->d_L + (npad + RZ) * ld;
-  // K^-1 = U U^T (lower 64x64 tiles) is accumulated panel by panel inside the split-panel schedule; the classic
-  // schedules (options "depth" 1|2, "lookahead" 0) form it in one product after the factorisation
-  const bool fused_kinv = h->lookahead != 0 && h->depth >= 3 && npad / nb >= h->split_min_blocks;   // same test as factor_loop's dispatch
+  // K^-1 = U U^T (lower 64x64 tiles) is accumulated panel by panel inside the split-panel schedule; the
+  // single-stream schedule forms it in one product after the factorisation
+  const bool fused_kinv = split;
   if (fused_kinv) { h->kinv_U = U; h->kinv_rows = n64; }
-  int frc = factor_loop(h, rows, npad + RZ);
+  int frc = factor_loop(h, primary_mats(h, rows), npad + RZ);
   h->kinv_U = nullptr; h->kinv_rows = 0;
   GPX_RET(frc);
 
@@ -1630,6 +944,12 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
     if (info != 0) for (int i = 0; i < o; ++i) grad_out[i] = NAN;
   }
   return info;
+}
+
+extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const double* y_minus_m, double* logp,
+                            double* grad_out, double* alpha_out) {
+  if (!h) return GPX_ERR_ARG;
+  return with_retry([&] { return lml_grad_once(h, p, y_minus_m, logp, grad_out, alpha_out); });
 }
 
 static void cached_params(gpx_handle* h, gpx_kernel_params* q) {
@@ -1724,49 +1044,55 @@ extern "C" int gpx_prior_cov(gpx_handle* h, const gpx_kernel_params* p, double n
 
 // ------------------------------------------------------------------------ MVN sampling
 
+// Cholesky of `batch` symmetric (m x m) matrices sitting in d_A2 (lower triangles, ld = npad, identity padding in place)
+// through the same blocked factorisation on the secondary buffers (the cached GP factor stays valid), then
+// Y = E L_c^T for `spad` rows of standard-normal draws per matrix (E in d_eps, Y in d_smp, both (spad, npad) per draw).
+static int sample_factor_and_draw(gpx_handle* h, int64_t m, int64_t nb, int64_t npad, int64_t spad, int batch) {
+  hipStream_t s = h->s_main;
+  Mats M2;
+  M2.A = h->d_A2; M2.L = h->d_L2; M2.W = h->d_W2; M2.npad = npad; M2.ld = npad; M2.rows_total = npad;
+  M2.nb = (int)nb; M2.batch = batch; M2.sA = npad * npad; M2.sW = npad * nb;
+  GPX_RET(factor_loop(h, M2));
+  GemmLaunch g;
+  g.A = h->d_eps; g.lda = npad; g.B = h->d_L2; g.ldb = npad; g.C = h->d_smp; g.ldc = npad;
+  g.M = spad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0;
+  g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 0;
+  g.batch = batch; g.sA = spad * npad; g.sB = npad * npad; g.sC = spad * npad;
+  (void)m;
+  return launch_gemm_nt(h, s, g);
+}
+
+static int sample_buffers(gpx_handle* h, int64_t nb, int64_t npad, int64_t spad, int batch) {
+  GPX_RET(ensure(h, &h->d_A2, &h->a2_cap, npad * npad * batch));
+  GPX_RET(ensure(h, &h->d_L2, &h->l2_cap, npad * npad * batch));
+  GPX_RET(ensure(h, &h->d_W2, &h->w2_cap, npad * nb * batch));
+  GPX_RET(ensure(h, &h->d_eps, &h->eps_cap, spad * npad * batch));
+  GPX_RET(ensure(h, &h->d_smp, &h->smp_cap, spad * npad * batch));
+  return ensure_events(h, (size_t)(npad / nb), (int)nb, batch);
+}
+
 // dist.MultivariateNormal(mean, cov).sample(key, (n,)) of gpax/gp.py:335-337:  out = mean + eps L_c^T,
-// L_c = chol(cov).  The (m x m) Cholesky runs through the same blocked factorisation (its own
-// buffers: the cached GP factor stays valid); the draws eps ~ N(0, I) come from the caller.
-extern "C" int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* cov, int64_t m, const double* eps,
-                              int64_t nsamp, double* out) {
-  if (!h) return GPX_ERR_ARG;
+// L_c = chol(cov); the draws eps ~ N(0, I) come from the caller.
+static int mvn_sample_once(gpx_handle* h, const double* mean, const double* cov, int64_t m, const double* eps,
+                           int64_t nsamp, double* out) {
   if (!cov || !eps || !out || m <= 0 || nsamp <= 0) { gpx_set_error(h, "gpx_mvn_sample: bad argument"); return GPX_ERR_ARG; }
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
   hipStream_t s = h->s_main;
-  const int sv_nb = h->nb;
   const int64_t nb = h->nb_auto ? (m <= 64 ? 64 : 128) : h->nb;   // the sample covariance is its own problem size
   const int64_t npad = round_up(m, nb), spad = round_up(nsamp, 64);
-  GPX_RET(ensure(h, &h->d_A2, &h->a2_cap, npad * npad));
-  GPX_RET(ensure(h, &h->d_L2, &h->l2_cap, npad * npad));
-  GPX_RET(ensure(h, &h->d_W2, &h->w2_cap, npad * nb));
-  GPX_RET(ensure(h, &h->d_S, &h->s_cap, 2 * spad * npad));
-  h->nb = (int)nb;
-  int erc = ensure_events(h, (size_t)(npad / nb));   // sizes its scratch by h->nb
-  h->nb = sv_nb;
-  GPX_RET(erc);
+  const int64_t sv_flags = h->s_flags, sv_mini = h->s_mini;
+  GPX_RET(sample_buffers(h, nb, npad, spad, 1));
   GPX_HIP_CHECK(h, hipMemcpy2DAsync(h->d_A2, (size_t)npad * sizeof(double), cov, (size_t)m * sizeof(double),
                                     (size_t)m * sizeof(double), (size_t)m, hipMemcpyHostToDevice, s));
   GPX_RET(launch_fill_identity_pad(h, s, h->d_A2, npad, m, npad, npad));
   GPX_HIP_CHECK(h, hipMemsetAsync(h->d_info, 0, sizeof(int), s));
-  // run the factor loop on the secondary buffers
-  std::swap(h->d_A, h->d_A2); std::swap(h->d_L, h->d_L2); std::swap(h->d_W, h->d_W2);
-  const int64_t sv_npad = h->npad, sv_ld = h->ld, sv_epad = h->epad;
-  h->npad = npad; h->ld = npad; h->epad = 0; h->nb = (int)nb;
-  int rc = factor_loop(h, npad);
-  double* Lc = h->d_L;
-  h->npad = sv_npad; h->ld = sv_ld; h->epad = sv_epad; h->nb = sv_nb;
-  std::swap(h->d_A, h->d_A2); std::swap(h->d_L, h->d_L2); std::swap(h->d_W, h->d_W2);
-  GPX_RET(rc);
-  double* E = h->d_S; double* Y = h->d_S + spad * npad;
-  GPX_HIP_CHECK(h, hipMemsetAsync(E, 0, (size_t)(spad * npad) * sizeof(double), s));
-  GPX_HIP_CHECK(h, hipMemcpy2DAsync(E, (size_t)npad * sizeof(double), eps, (size_t)m * sizeof(double),
+  GPX_HIP_CHECK(h, hipMemsetAsync(h->d_eps, 0, (size_t)(spad * npad) * sizeof(double), s));
+  GPX_HIP_CHECK(h, hipMemcpy2DAsync(h->d_eps, (size_t)npad * sizeof(double), eps, (size_t)m * sizeof(double),
                                     (size_t)m * sizeof(double), (size_t)nsamp, hipMemcpyHostToDevice, s));
-  GemmLaunch g;
-  g.A = E; g.lda = npad; g.B = Lc; g.ldb = npad; g.C = Y; g.ldc = npad;
-  g.M = spad; g.N = npad; g.K = npad; g.alpha = 1.0; g.beta = 0.0;
-  g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 0;
-  GPX_RET(launch_gemm_nt(h, s, g));
-  GPX_HIP_CHECK(h, hipMemcpy2DAsync(out, (size_t)m * sizeof(double), Y, (size_t)npad * sizeof(double),
+  const int rc = sample_factor_and_draw(h, m, nb, npad, spad, 1);
+  h->s_flags = sv_flags; h->s_mini = sv_mini;
+  GPX_RET(rc);
+  GPX_HIP_CHECK(h, hipMemcpy2DAsync(out, (size_t)m * sizeof(double), h->d_smp, (size_t)npad * sizeof(double),
                                     (size_t)m * sizeof(double), (size_t)nsamp, hipMemcpyDeviceToHost, s));
   int info = 0;
   GPX_RET(read_info(h, &info));
@@ -1776,11 +1102,15 @@ extern "C" int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* c
   return info;
 }
 
+extern "C" int gpx_mvn_sample(gpx_handle* h, const double* mean, const double* cov, int64_t m, const double* eps,
+                              int64_t nsamp, double* out) {
+  if (!h) return GPX_ERR_ARG;
+  return with_retry([&] { return mvn_sample_once(h, mean, cov, m, eps, nsamp, out); });
+}
+
 // ------------------------------------------------------------------ fused fit+predict
 
-static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
-  const int64_t m = fp.m_rows;
-  hipStream_t s = h->s_main;
+static EpilogueLaunch fit_predict_epilogue(gpx_handle* h, int64_t m) {
   EpilogueLaunch e;
   e.L = h->d_L; e.ld = h->ld; e.n = h->n; e.z = h->d_L + (h->npad + m) * h->ld;
   e.vt = h->d_L + h->npad * h->ld; e.vt_ld = h->ld; e.m = m;
@@ -1788,16 +1118,27 @@ static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
   e.prior_diag = 0.0; e.dev_prior_diag = h->d_hyp + 2 * h->d + 3;
   e.scal = h->d_scal; e.mean = h->d_mean; e.var = h->d_var;
   e.z_copy = h->d_z; e.npad = h->npad;   // keep z for later posterior calls against the cached factor
-  // split epilogue (split-panel schedule, three block columns or more): see side() in factor_loop_split
+  e.batch = h->batch; e.s_mat = h->s_mat; e.s_out = h->s_out; e.s_zcopy = h->s_z; e.s_mnew = h->s_mnew; e.s_hyp = h->s_hyp;
+  e.s_part = h->s_epart;
+  return e;
+}
+
+static int fit_predict_enqueue(gpx_handle* h, const FactorPlan& fp) {
+  const int64_t m = fp.m_rows;
+  hipStream_t s = h->s_main;
+  const double B = (double)h->batch;
+  h->s_epart = 2 + 2 * std::max<int64_t>(m, 1);
+  EpilogueLaunch e = fit_predict_epilogue(h, m);
+  // split epilogue (split-panel schedule, three block columns or more): see SplitSchedule::panel (schedule.hip)
   h->epi = nullptr; h->epi_split_col = 0;
-  if (h->epi_split && !h->in_capture && h->prof_mode != 1 && h->lookahead != 0 && h->depth >= 3 && h->npad / h->nb >= std::max(3, h->split_min_blocks)) {
-    GPX_RET(ensure(h, &h->d_epart, &h->epart_cap, 2 + 2 * std::max<int64_t>(m, 1)));
+  if (h->prof_mode != 1 && h->lookahead != 0 && h->npad / h->nb >= std::max(3, h->split_min_blocks)) {
+    GPX_RET(ensure(h, &h->d_epart, &h->epart_cap, h->s_epart * h->batch));
     h->epi = &e;
   }
   const int frc = factor_enqueue(h, fp, nullptr);
   h->epi = nullptr;
   GPX_RET(frc);
-  prof_begin(h, s, GPX_STAGE_EPILOGUE, 4.0 * (m + 1.0) * h->n, 8.0 * (m + 2.0) * h->n);
+  prof_begin(h, s, GPX_STAGE_EPILOGUE, B * 4.0 * (m + 1.0) * h->n, B * 8.0 * (m + 2.0) * h->n);
   if (h->epi_split_col > 0) GPX_RET(launch_epilogue_final(h, s, e, h->epi_split_col, h->d_epart));
   else GPX_RET(launch_epilogue(h, s, e));
   prof_end(h, s);
@@ -1812,60 +1153,16 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
   hipStream_t s = h->s_main;
   GPX_RET(factor_prepare(h, m, true));
   h->d_var = h->d_mean + std::max<int64_t>(m, 1);
+  h->s_r = 0; h->s_mnew = 0;
   FactorPlan fp;
   double noise_scalar;
   GPX_RET(upload_params(h, s, p, h->n, h->d, &fp.noise_dev, &noise_scalar, new_noise));
   fp.kind = p->kind; fp.apply_noise = p->apply_noise; fp.m_rows = m; fp.with_r = true; fp.want_k = false;
-
-  if (h->use_graph && !h->prof_mode) {
-    // One captured graph per (shape, kernel kind, buffer addresses); hyper-parameter VALUES live in
-    // d_hyp / d_noise / d_r / d_mnew, so the same graph is replayed for every hyper-parameter draw.
-    char key[512];
-    snprintf(key, sizeof(key), "%d|%d|%lld|%lld|%d|%d|%d|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p|%p", fp.kind, fp.apply_noise,
-             (long long)h->n, (long long)m, h->d, h->nb, h->lookahead * 4 + h->depth + 16 * h->pair_min + 4096 * h->quad_min, (void*)h->d_A, (void*)h->d_L, (void*)h->d_W,
-             (void*)h->d_x, (void*)h->d_xnew, (void*)h->d_r, (void*)(h->have_mnew ? h->d_mnew : nullptr),
-             (void*)h->d_hyp, (void*)fp.noise_dev, (void*)h->d_mean, (void*)h->d_z);
-    auto it = h->graphs.find(key);
-    if (it == h->graphs.end() && !h->graph_warm.count(key)) {
-      // first call of a shape runs eagerly: lazy one-time initialisation (code-object loading, first use of the
-      // side streams) inside a stream capture crashed the ROCm 7.2 runtime; the capture happens on the second call
-      h->graph_warm.insert(key);
-      GPX_RET(fit_predict_enqueue(h, fp));
-      factor_commit(h, p, m, true);
-      return GPX_OK;
-    }
-    if (it == h->graphs.end()) {
-      hipGraph_t graph = nullptr;
-      const bool trace = getenv("GPX_TRACE") != nullptr;
-      if (trace) fprintf(stderr, "[gpx] begin capture\n");
-      GPX_HIP_CHECK(h, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      h->in_capture = true;
-      int rc = fit_predict_enqueue(h, fp);
-      h->in_capture = false;
-      if (trace) fprintf(stderr, "[gpx] enqueue rc=%d, end capture\n", rc);
-      hipError_t ce = hipStreamEndCapture(s, &graph);
-      if (trace) fprintf(stderr, "[gpx] end capture: %s\n", hipGetErrorString(ce));
-      if (rc != GPX_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      if (ce != hipSuccess) { gpx_set_error(h, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce)); return GPX_ERR_HIP; }
-      hipGraphExec_t exec = nullptr;
-      ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      if (trace) fprintf(stderr, "[gpx] instantiate: %s\n", hipGetErrorString(ce));
-      (void)hipGraphDestroy(graph);
-      if (ce != hipSuccess) { gpx_set_error(h, std::string("hipGraphInstantiate: ") + hipGetErrorString(ce)); return GPX_ERR_HIP; }
-      if (h->graphs.size() >= 16) {  // bound the cache
-        for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
-        h->graphs.clear();
-      }
-      it = h->graphs.emplace(key, exec).first;
-    }
-    GPX_HIP_CHECK(h, hipGraphLaunch(it->second, s));
-  } else {
-    prof_begin(h, s, GPX_STAGE_FACTOR_TOTAL, 0.0, 0.0);
-    GPX_RET(fit_predict_enqueue(h, fp));
-    if (h->prof_mode) {  // close the FACTOR_TOTAL bracket (first pending of this call)
-      for (size_t i = h->pending.size(); i-- > 0;)
-        if (h->pending[i].stage == GPX_STAGE_FACTOR_TOTAL) { (void)hipEventRecord(h->pending[i].b, s); break; }
-    }
+  prof_begin(h, s, GPX_STAGE_FACTOR_TOTAL, 0.0, 0.0);
+  GPX_RET(fit_predict_enqueue(h, fp));
+  if (h->prof_mode) {  // close the FACTOR_TOTAL bracket (first pending of this call)
+    for (size_t i = h->pending.size(); i-- > 0;)
+      if (h->pending[i].stage == GPX_STAGE_FACTOR_TOTAL) { (void)hipEventRecord(h->pending[i].b, s); break; }
   }
   factor_commit(h, p, m, true);
   return GPX_OK;
@@ -1875,9 +1172,7 @@ extern "C" int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, 
   if (!h) return GPX_ERR_ARG;
   if (!h->have_factor || !h->r_in_factor) { gpx_set_error(h, "gpx_fetch_results: no fit_predict results"); return GPX_ERR_STATE; }
   GPX_HIP_CHECK(h, hipSetDevice(h->device));
-  hipStream_t s = h->s_main;
   const int64_t m = h->m_in_factor;
-  (void)s;
   // one copy: [scal | info | mean(m) | var(m)] (d_var = d_mean + max(m, 1), set by gpx_fit_predict_async)
   const double* blk;
   GPX_RET(fetch_block(h, m > 0 ? 2 * m : 0, &blk));
@@ -1894,9 +1189,243 @@ extern "C" int gpx_fit_predict(gpx_handle* h, const gpx_kernel_params* p, const 
                                const double* m_new, double new_noise, double* logp, double* mean_out,
                                double* var_out) {
   if (!h) return GPX_ERR_ARG;
-  GPX_RET(gpx_set_targets(h, y_minus_m, m_new));
-  GPX_RET(gpx_fit_predict_async(h, p, new_noise));
-  return gpx_fetch_results(h, logp, mean_out, var_out);
+  return with_retry([&]() -> int {
+    GPX_RET(gpx_set_targets(h, y_minus_m, m_new));
+    GPX_RET(gpx_fit_predict_async(h, p, new_noise));
+    return gpx_fetch_results(h, logp, mean_out, var_out);
+  });
+}
+
+// ---------------------------------------------------------------- batched hyper-parameter draws
+
+// Upload the per-draw targets: r (batch, n) and, optionally, m_new (batch, m).
+static int set_targets_batch(gpx_handle* h, int batch, const double* y_minus_m, const double* m_new) {
+  const int64_t n = h->n, m = h->m;
+  hipStream_t s = h->s_main;
+  GPX_RET(ensure(h, &h->d_r, &h->r_cap, n * batch));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)(n * batch) * sizeof(double), hipMemcpyHostToDevice, s));
+  h->have_r = true; h->s_r = n;
+  h->have_mnew = false; h->s_mnew = 0;
+  if (m_new && m > 0) {
+    GPX_RET(ensure(h, &h->d_mnew, &h->mnew_cap, m * batch));
+    GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_mnew, m_new, (size_t)(m * batch) * sizeof(double), hipMemcpyHostToDevice, s));
+    h->have_mnew = true; h->s_mnew = m;
+  }
+  return GPX_OK;
+}
+
+// After a batched call the handle's single-draw caches (factor, z, targets) describe draw 0 only in part: drop them.
+static void batch_invalidate(gpx_handle* h) {
+  h->have_factor = false; h->have_z = false; h->have_r = false; h->have_mnew = false;
+  h->batch = 1; h->s_r = 0; h->s_mnew = 0; h->s_noise = 0;
+}
+
+static int fit_predict_batch_once(gpx_handle* h, int batch, const gpx_kernel_params* params, const double* y_minus_m,
+                                  const double* m_new, const double* new_noise, double* logp, double* mean_out,
+                                  double* var_out, int32_t* info_out) {
+  const int64_t m = h->m, n = h->n;
+  hipStream_t s = h->s_main;
+  GPX_RET(factor_prepare(h, m, true, batch));
+  h->d_var = h->d_mean + std::max<int64_t>(m, 1);
+  GPX_RET(set_targets_batch(h, batch, y_minus_m, m_new));
+  FactorPlan fp;
+  GPX_RET(upload_params_batch(h, s, params, batch, n, h->d, &fp.noise_dev, new_noise));
+  fp.kind = params->kind; fp.apply_noise = params->apply_noise; fp.m_rows = m; fp.with_r = true; fp.want_k = false;
+  const int erc = fit_predict_enqueue(h, fp);
+  const double* blk = nullptr;
+  int frc = erc == GPX_OK ? fetch_block(h, 0, &blk, batch) : erc;
+  const int64_t so = h->s_out;
+  batch_invalidate(h);
+  GPX_RET(frc);
+  int worst = 0;
+  for (int b = 0; b < batch; ++b) {
+    const double* q = blk + so * b;
+    const int info = reinterpret_cast<const int*>(q + 8)[0];
+    GPX_RET(check_handover(h, info));
+    if (info_out) info_out[b] = info;
+    if (info > worst) worst = info;
+    if (logp) logp[b] = -0.5 * q[1] - q[0] - 0.5 * (double)n * log(2.0 * M_PI);
+    if (mean_out && m > 0) memcpy(mean_out + m * b, q + GPX_OUT_HEAD, (size_t)m * sizeof(double));
+    if (var_out && m > 0) memcpy(var_out + m * b, q + GPX_OUT_HEAD + m, (size_t)m * sizeof(double));
+  }
+  return worst;
+}
+
+extern "C" int gpx_fit_predict_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* params, const double* y_minus_m,
+                                     const double* m_new, const double* new_noise, double* logp, double* mean_out,
+                                     double* var_out, int32_t* info_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (batch < 1 || batch > 4096 || !params || !y_minus_m) { gpx_set_error(h, "gpx_fit_predict_batch: bad argument"); return GPX_ERR_ARG; }
+  if (h->n <= 0) { gpx_set_error(h, "gpx_fit_predict_batch: call gpx_set_train first"); return GPX_ERR_STATE; }
+  return with_retry([&] { return fit_predict_batch_once(h, batch, params, y_minus_m, m_new, new_noise, logp, mean_out, var_out, info_out); });
+}
+
+// cov = k_new - V^T V (draw b: V^T = the k_cross border rows of its factor), lower triangle, into d_A2 with identity padding
+static int posterior_cov_to_A2(gpx_handle* h, int kind, int64_t m, int64_t npad2, int batch, bool conditioned) {
+  hipStream_t s = h->s_main;
+  const int d = h->d;
+  GramLaunch c;
+  c.kind = kind; c.d = d; c.k_scale = 0.0; c.hyp = h->d_hyp; c.dev_scalars = h->d_hyp + 2 * d;
+  c.x1 = h->d_xnew; c.x2 = h->d_xnew; c.n1 = m; c.n2 = m; c.out = h->d_A2; c.ld = npad2;
+  c.lower_only = 1; c.diag_rule = 1; c.noise = nullptr; c.noise_scalar = 0.0; c.jitter = 0.0;
+  c.batch = batch; c.s_out = npad2 * npad2; c.s_hyp = h->s_hyp;
+  GPX_RET(launch_gram(h, s, c));
+  if (conditioned) {
+    // rows [m, m64) of the border are not V^T (the z row, zero rows): the update writes rubbish into the padding of the
+    // tiles it touches, and the identity padding is laid over it afterwards
+    const int64_t m64 = round_up(m, 64);
+    GemmLaunch u;
+    u.A = h->d_L + h->npad * h->ld; u.lda = h->ld; u.B = u.A; u.ldb = h->ld; u.C = h->d_A2; u.ldc = npad2;
+    u.M = m64; u.N = m64; u.K = h->npad; u.alpha = -1.0; u.beta = 1.0;
+    u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 0;
+    u.batch = batch; u.sA = h->s_mat; u.sB = h->s_mat; u.sC = npad2 * npad2;
+    GPX_RET(launch_gemm_nt(h, s, u));
+  }
+  return launch_fill_identity_pad(h, s, h->d_A2, npad2, m, npad2, npad2, batch, npad2 * npad2);
+}
+
+__global__ void sample_finish_kernel(const double* smp, int64_t ld_s, int64_t s_smp, const double* mean, int64_t s_mean,
+                                     int64_t m, int64_t nsamp, double* out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y, b = blockIdx.z;
+  if (c >= m) return;
+  const double mu = mean ? mean[b * s_mean + c] : 0.0;
+  out[(b * nsamp + r) * m + c] = mu + smp[b * s_smp + r * ld_s + c];
+}
+
+// _sample_gp_given_single_hp (gpax/gp.py:314-338) for `batch` hyper-parameter draws in one schedule -- what jax.vmap does
+// with it in _sample_prior / _sample_posterior (gpax/gp.py:352-365, 382-391): per draw, posterior (or prior) mean and
+// covariance at the resident x_new, sd = sqrt(diag cov), and nsamp MVN draws mean + eps chol(cov)^T.  The covariance never
+// leaves HBM.
+static int sample_batch_once(gpx_handle* h, int batch, const gpx_kernel_params* params, const double* y_minus_m,
+                             const double* m_new, const double* new_noise, const double* eps, int64_t nsamp, int conditioned,
+                             double* mean_out, double* sd_out, double* samples_out, int32_t* info_out) {
+  const int64_t m = h->m, n = h->n;
+  hipStream_t s = h->s_main;
+  const int64_t nb2 = h->nb_auto ? (m <= 64 ? 64 : 128) : h->nb;
+  const int64_t npad2 = round_up(m, nb2), spad = round_up(nsamp, 64);
+  FactorPlan fp;
+  if (conditioned) {
+    GPX_RET(factor_prepare(h, m, true, batch));
+    h->d_var = h->d_mean + std::max<int64_t>(m, 1);
+    GPX_RET(set_targets_batch(h, batch, y_minus_m, m_new));
+    GPX_RET(upload_params_batch(h, s, params, batch, n, h->d, &fp.noise_dev, new_noise));
+    fp.kind = params->kind; fp.apply_noise = params->apply_noise; fp.m_rows = m; fp.with_r = true; fp.want_k = false;
+    GPX_RET(fit_predict_enqueue(h, fp));
+  } else {
+    GPX_HIP_CHECK(h, hipSetDevice(h->device));
+    h->batch = batch;
+    GPX_RET(ensure_out(h, 2 * std::max<int64_t>(m, 1), batch));
+    GPX_HIP_CHECK(h, hipMemsetAsync(h->d_out, 0, (size_t)(h->s_out * batch) * sizeof(double), s));
+    const double* nd;
+    gpx_kernel_params* q = const_cast<gpx_kernel_params*>(params);   // the prior covariance carries new_noise only: the per-row noise is ignored
+    std::vector<gpx_kernel_params> tmp(q, q + batch);
+    for (auto& t : tmp) { t.n_noise = 0; t.k_noise = nullptr; }
+    GPX_RET(upload_params_batch(h, s, tmp.data(), batch, m, h->d, &nd, new_noise));
+    h->have_mnew = false; h->s_mnew = 0;
+    if (m_new) {
+      GPX_RET(ensure(h, &h->d_mnew, &h->mnew_cap, m * batch));
+      GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_mnew, m_new, (size_t)(m * batch) * sizeof(double), hipMemcpyHostToDevice, s));
+      h->have_mnew = true; h->s_mnew = m;
+    }
+  }
+  // the hyper-parameter block carries prior_diag = k(x*,x*) + new_noise + jitter; the covariance build needs the noise and
+  // jitter themselves on the diagonal: scalars {k_scale, new_noise, jitter} per draw in a second, transient block
+  {
+    const int64_t sh = h->s_hyp; const int d = h->d;
+    std::vector<double> hyp2((size_t)(sh * batch));
+    for (int b = 0; b < batch; ++b) {
+      const gpx_kernel_params* p = params + b;
+      double* hp = hyp2.data() + sh * b;
+      for (int k = 0; k < d; ++k) {
+        hp[k] = p->k_length[p->n_length == 1 ? 0 : k];
+        hp[d + k] = (p->kind == GPX_PERIODIC) ? p->k_period[p->n_period == 1 ? 0 : k] : 1.0;
+      }
+      hp[2 * d] = p->k_scale; hp[2 * d + 1] = new_noise ? new_noise[b] : 0.0; hp[2 * d + 2] = p->k_jitter; hp[2 * d + 3] = 0.0;
+    }
+    GPX_RET(ensure(h, &h->d_vec, &h->vec_cap, std::max<int64_t>(sh * batch, 2 * h->npad)));
+    GPX_RET(upload_small(h, s, h->d_vec, hyp2.data(), (int64_t)hyp2.size()));
+  }
+  const int64_t sv_flags = h->s_flags, sv_mini = h->s_mini;
+  GPX_RET(sample_buffers(h, nb2, npad2, spad, batch));
+  {
+    double* sv_hyp = h->d_hyp; h->d_hyp = h->d_vec;
+    const int crc = posterior_cov_to_A2(h, params->kind, m, npad2, batch, conditioned != 0);
+    h->d_hyp = sv_hyp;
+    GPX_RET(crc);
+  }
+  GPX_HIP_CHECK(h, hipMemsetAsync(h->d_eps, 0, (size_t)(spad * npad2 * batch) * sizeof(double), s));
+  for (int b = 0; b < batch; ++b)
+    GPX_HIP_CHECK(h, hipMemcpy2DAsync(h->d_eps + spad * npad2 * b, (size_t)npad2 * sizeof(double), eps + nsamp * m * b, (size_t)m * sizeof(double),
+                                      (size_t)m * sizeof(double), (size_t)nsamp, hipMemcpyHostToDevice, s));
+  const int src = sample_factor_and_draw(h, m, nb2, npad2, spad, batch);
+  h->s_flags = sv_flags; h->s_mini = sv_mini;
+  GPX_RET(src);
+  // samples = mean + Y: one launch into a dense (batch, nsamp, m) block, one copy back
+  GPX_RET(ensure(h, &h->d_S, &h->s_cap, nsamp * m * batch));
+  {
+    const double* meanp = conditioned ? h->d_mean : (h->have_mnew ? h->d_mnew : nullptr);
+    const int64_t s_mean = conditioned ? h->s_out : h->s_mnew;
+    hipLaunchKernelGGL(sample_finish_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)nsamp, (unsigned)batch), dim3(256), 0, s,
+                       h->d_smp, npad2, spad * npad2, meanp, s_mean, m, nsamp, h->d_S);
+    GPX_HIP_CHECK(h, hipGetLastError());
+    GPX_HIP_CHECK(h, hipMemcpyAsync(samples_out, h->d_S, (size_t)(nsamp * m * batch) * sizeof(double), hipMemcpyDeviceToHost, s));
+  }
+  const double* blk = nullptr;
+  const int frc = fetch_block(h, 0, &blk, batch);
+  const int64_t so = h->s_out;
+  const bool had_mnew = h->have_mnew;
+  batch_invalidate(h);
+  GPX_RET(frc);
+  int worst = 0;
+  for (int b = 0; b < batch; ++b) {
+    const double* q = blk + so * b;
+    const int info = reinterpret_cast<const int*>(q + 8)[0];
+    GPX_RET(check_handover(h, info));
+    if (info_out) info_out[b] = info;
+    if (info > worst) worst = info;
+    if (mean_out) {
+      if (conditioned) memcpy(mean_out + m * b, q + GPX_OUT_HEAD, (size_t)m * sizeof(double));
+      else for (int64_t c = 0; c < m; ++c) mean_out[m * b + c] = (had_mnew && m_new) ? m_new[m * b + c] : 0.0;
+    }
+    if (sd_out) {   // sd = sqrt(diag cov) (gpax/gp.py:338): diag cov = k(x*,x*) + new_noise + jitter - |V_c|^2, the epilogue's variance
+      const gpx_kernel_params* p = params + b;
+      const double pd = kernel_diag_value(p->kind, p->k_scale) + ((new_noise ? new_noise[b] : 0.0) + p->k_jitter);
+      for (int64_t c = 0; c < m; ++c) sd_out[m * b + c] = sqrt(conditioned ? q[GPX_OUT_HEAD + m + c] : pd);
+    }
+  }
+  return worst;
+}
+
+extern "C" int gpx_sample_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* params, const double* y_minus_m,
+                                const double* m_new, const double* new_noise, const double* eps, int64_t nsamp,
+                                int32_t conditioned, double* mean_out, double* sd_out, double* samples_out, int32_t* info_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (batch < 1 || batch > 4096 || !params || !eps || !samples_out || nsamp <= 0 || (conditioned && !y_minus_m)) {
+    gpx_set_error(h, "gpx_sample_batch: bad argument"); return GPX_ERR_ARG;
+  }
+  if (h->m <= 0 || !h->d_xnew) { gpx_set_error(h, "gpx_sample_batch: call gpx_set_test first"); return GPX_ERR_STATE; }
+  if (conditioned && h->n <= 0) { gpx_set_error(h, "gpx_sample_batch: call gpx_set_train first"); return GPX_ERR_STATE; }
+  return with_retry([&] {
+    return sample_batch_once(h, batch, params, y_minus_m, m_new, new_noise, eps, nsamp, conditioned, mean_out, sd_out, samples_out, info_out);
+  });
+}
+
+// ------------------------------------------------------------------------- runtime identity
+
+// Which HIP runtime this library is actually bound to.  A process that imports PyTorch first maps torch's bundled
+// libamdhip64.so (SONAME libamdhip64.so.7, ROCm 7.0) and this library's NEEDED libamdhip64.so.7 then resolves to THAT
+// copy instead of the /opt/rocm one it was compiled against; imported the other way round, two HIP and two HSA runtimes
+// are mapped.  Round 1's hipStreamEndCapture crash lived in exactly that configuration.  Format:
+// "built=<HIP_VERSION> runtime=<hipRuntimeGetVersion> path=<file the runtime was loaded from>".
+extern "C" int gpx_runtime_info(char* buf, int len) {
+  if (!buf || len <= 0) return GPX_ERR_ARG;
+  int rt = 0;
+  (void)hipRuntimeGetVersion(&rt);
+  Dl_info di;
+  const char* path = "?";
+  if (dladdr(reinterpret_cast<void*>(&hipRuntimeGetVersion), &di) && di.dli_fname) path = di.dli_fname;
+  snprintf(buf, (size_t)len, "built=%d runtime=%d path=%s", HIP_VERSION, rt, path);
+  return (rt / 100000 == HIP_VERSION / 100000) ? GPX_OK : GPX_ERR_UNSUPPORTED;   // same major.minor (version = major*1e7 + minor*1e5 + patch)
 }
 
 // ------------------------------------------------------------------- measurement API

@@ -226,8 +226,10 @@ extern "C" int gpx_dist_step_diag(gpx_handle* h, int64_t k) {
   if (owner_of(D, k) != D.rank) return GPX_OK;
   const int nb = h->nb;
   const int64_t s = slot_of(D, k), c0 = k * nb;
-  return launch_potrf_diag(h, h->s_main, nb, D.A + s * nb * D.ld + c0, D.ld, D.L + s * nb * D.ld + c0, D.ld, D.W,
-                           h->d_info, (int)c0);
+  PotrfLaunch p;
+  p.nb = nb; p.A = D.A + s * nb * D.ld + c0; p.lda = D.ld; p.L = D.L + s * nb * D.ld + c0; p.ldl = D.ld; p.W = D.W;
+  p.info = h->d_info; p.col0 = (int)c0;
+  return launch_potrf_diag(h, h->s_main, p);
 }
 
 extern "C" int gpx_dist_step_panel(gpx_handle* h, int64_t k) {
@@ -309,8 +311,10 @@ extern "C" int gpx_dist_step_diag_early(gpx_handle* h, int64_t k1) {
   u.M = nb; u.N = nb; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
   u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
   GPX_RET(launch_gemm_nt(h, h->s_main2, u));
-  return launch_potrf_diag(h, h->s_main2, nb, D.A + sl * nb * D.ld + c1, D.ld, D.L + sl * nb * D.ld + c1, D.ld, D.W,
-                           h->d_info, (int)c1);
+  PotrfLaunch p;
+  p.nb = nb; p.A = D.A + sl * nb * D.ld + c1; p.lda = D.ld; p.L = D.L + sl * nb * D.ld + c1; p.ldl = D.ld; p.W = D.W;
+  p.info = h->d_info; p.col0 = (int)c1;
+  return launch_potrf_diag(h, h->s_main2, p);
 }
 
 extern "C" int gpx_dist_step_update(gpx_handle* h, int64_t k) {

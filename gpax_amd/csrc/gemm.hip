@@ -31,8 +31,10 @@ struct GemmArgs {
   int64_t row_off, col_off;
   int lower, b_lower_tri;
   int a_upper_tri;   // A[m][k] == 0 for k < m (rows of an upper-triangular factor): K below the tile's first row is dead
-  // XCD-aware 1-D tile map of the lower trapezoid (map_S > 0; row_off == col_off): see tile_from_block()
-  int map_S; int64_t map_nti, map_ntj, map_nsj, map_nsuper;
+  // map_S < 0: 1-D row-major enumeration of the lower trapezoid's tiles (row_off == col_off), map_ntj tile columns
+  int map_S; int64_t map_ntj;
+  // batched hyper-parameter draws: blockIdx.z = draw, per-draw strides (0: shared)
+  int64_t sA, sB, sC, s_flag, s_info;
   // block-cyclic row distribution (distributed factorisation): local row m is global row
   // ((m / cyc_nb) * cyc_P + cyc_r) * cyc_nb + m % cyc_nb;  cyc_P <= 1: rows are global already
   int cyc_P, cyc_r, cyc_nb;
@@ -48,16 +50,6 @@ __device__ __forceinline__ int64_t tile_global_row(const GemmArgs& g, int64_t m0
   if (g.cyc_P > 1) r = ((r / g.cyc_nb) * g.cyc_P + g.cyc_r) * g.cyc_nb + r % g.cyc_nb;
   return r;
 }
-
-// Lower-trapezoid tile for a 1-D grid, XCD-aware.  Workgroups are dealt round-robin over the 8 XCDs (private
-// L2 each) by linear id, so with the plain 2-D grid every XCD streams the WHOLE panel through its L2 (measured:
-// 43 MB of panel fetches beside 36 MB of C per launch at N=4096).  Here the id is read as (XCD label x = id % 8,
-// sequence number id / 8): XCD label x works through the S x S-tile super-tiles x, x+8, x+16, ... of the lower
-// trapezoid, S*S consecutive sequence numbers each, so the tiles resident on one XCD at a time share S tile rows
-// of A and S tile rows of B (panel traffic ~2/S of the C traffic), and no workgroup is spent on tiles above the
-// diagonal except inside the diagonal super-tiles.  Returns false for an empty slot.  Placement is a speed
-// matter only: every tile is computed exactly once whatever XCD it lands on.
-__device__ __forceinline__ bool tile_from_block(const struct GemmArgs& g, int64_t& ti, int64_t& tj);
 
 #define GEMM_BK 32
 #ifndef GEMM_MAIN_WAVES
@@ -108,27 +100,14 @@ __device__ unsigned long long* g_gemm_stamps;
 #define GEMM_STAMP(slot) do { } while (0)
 #endif
 
-__device__ __forceinline__ bool tile_from_block(const GemmArgs& g, int64_t& ti, int64_t& tj) {
-  const int64_t b = blockIdx.x;
-  const int x = (int)(b & 7);
-  const int64_t seq = b >> 3;
-  const int S = g.map_S, S2 = S * S;
-  const int64_t u = (seq / S2) * 8 + x;
-  const int slot = (int)(seq % S2);
-  if (u >= g.map_nsuper) return false;
-  const int64_t nsj = g.map_nsj, ntri = nsj * (nsj + 1) / 2;
-  int64_t si, sj;
-  if (u < ntri) {   // row si of the triangular part holds si + 1 super-tiles
-    si = (int64_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
-    while (si * (si + 1) / 2 > u) --si;
-    while ((si + 1) * (si + 2) / 2 <= u) ++si;
-    sj = u - si * (si + 1) / 2;
-  } else {
-    const int64_t v = u - ntri;
-    si = nsj + v / nsj; sj = v % nsj;
-  }
-  ti = si * S + slot / S; tj = sj * S + slot % S;
-  return ti < g.map_nti && tj < g.map_ntj && tj <= ti;
+// draw b of a batched launch works on its own matrices / flags
+__device__ __forceinline__ void batch_offset(GemmArgs& g) {
+  const int64_t z = blockIdx.z;
+  if (z == 0) return;
+  g.A += z * g.sA; g.B += z * g.sB; g.C += z * g.sC;
+  if (g.signal) g.signal += z * g.s_flag;
+  if (g.wait_flag) g.wait_flag += z * g.s_flag;
+  if (g.wait_info) g.wait_info += z * g.s_info;
 }
 
 // ROLE only names the instantiation (0: the bulk trailing update, 1: look-ahead column updates and near blocks on the panel
@@ -147,12 +126,9 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   GEMM_TL(4, g.M, g.N * 1000000 + g.K);
+  batch_offset(g);
   int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
-  if (g.map_S > 0) {
-    int64_t ti, tj;
-    if (!tile_from_block(g, ti, tj)) return;
-    m0 = ti * BM; n0 = tj * BN;
-  } else if (g.map_S < 0) {
+  if (g.map_S < 0) {
     // 1-D row-major enumeration of the lower trapezoid's tiles (row_off == col_off): no empty workgroups, and the
     // round-robin deal of consecutive workgroup ids over the 8 XCDs stays balanced whatever the grid width (with
     // the 2-D grid and a width that is a multiple of 8 tiles, XCD x owns the tile columns = x mod 8 and XCD 0
@@ -315,141 +291,10 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   GEMM_TL_END();
 }
 
-// ---- persistent, tile-pipelined variant of the 64x64 kernel (the trailing update) ------------
-// With K = nb = 128 a 64x64 tile is only four K-chunks of MFMA work, so in the plain kernel the
-// exposed first load and the C read-modify-write of every tile cost about a third of the time.
-// Here a workgroup walks a strided list of tiles and treats (tile, K-chunk) pairs as ONE flat
-// software pipeline: while chunk c of tile t is in the MFMAs the registers already hold the next
-// chunk -- of the same tile or of the next one -- and the next tile's C tile is fetched two
-// stages ahead into spare registers; the store of tile t overlaps the first chunk of tile t+1.
-// Tiles are enumerated over the lower trapezoid only (no empty workgroups).
-#ifndef GEMM_PERSIST_WAVES
-#define GEMM_PERSIST_WAVES 2
-#endif
-__global__ __launch_bounds__(256, GEMM_PERSIST_WAVES) void gemm_nt_persist_kernel(GemmArgs g, int ntj, int64_t ntiles) {
-  constexpr int BM = 64, BN = 64, TM = 2, TN = 2;
-  constexpr int NA = BM * (GEMM_BK / 2) / 256, NBc = BN * (GEMM_BK / 2) / 256;
-  __shared__ __attribute__((aligned(16))) double As[BM * GEMM_LDT];
-  __shared__ __attribute__((aligned(16))) double Bs[BN * GEMM_LDT];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int fr = lane & 15, fk = lane >> 4;
-  const int nchunks = (int)(g.K / GEMM_BK);
-  const double cscale = g.beta / g.alpha;
-  const int64_t ntri = (int64_t)ntj * (ntj + 1) / 2;   // tiles in the triangular top part
-
-  auto decode = [&](int64_t t, int64_t& m0, int64_t& n0) {
-    int64_t ti, tj;
-    if (t < ntri) {   // row ti holds ti+1 tiles
-      ti = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-      while (ti * (ti + 1) / 2 > t) --ti;
-      while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-      tj = t - ti * (ti + 1) / 2;
-    } else {          // full rows below the square part
-      const int64_t u = t - ntri;
-      ti = ntj + u / ntj;
-      tj = u % ntj;
-    }
-    m0 = ti * BM; n0 = tj * BN;
-  };
-
-  v2d ra[NA], rb[NBc];
-  auto load_chunk = [&](int64_t m0, int64_t n0, int64_t k0) {
-    const double* Ag = g.A + m0 * g.lda + k0;
-    const double* Bg = g.B + n0 * g.ldb + k0;
-#pragma unroll
-    for (int it = 0; it < NA; ++it) {
-      const int c = tid + it * 256;
-      ra[it] = *reinterpret_cast<const v2d*>(Ag + (int64_t)(c >> 4) * g.lda + 2 * (c & 15));
-    }
-#pragma unroll
-    for (int it = 0; it < NBc; ++it) {
-      const int c = tid + it * 256;
-      rb[it] = *reinterpret_cast<const v2d*>(Bg + (int64_t)(c >> 4) * g.ldb + 2 * (c & 15));
-    }
-  };
-  v4d cnext[TM][TN];
-  auto load_c = [&](int64_t m0, int64_t n0) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const double* cp = g.C + (m0 + wm * 32 + i * 16 + fk) * g.ldc + n0 + wn * 32 + j * 16 + fr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cnext[i][j][r] = cp[(int64_t)(4 * r) * g.ldc];
-      }
-  };
-
-  int64_t t = blockIdx.x;
-  if (t >= ntiles) return;
-  int64_t m0, n0, m1 = 0, n1 = 0;
-  decode(t, m0, n0);
-  load_chunk(m0, n0, 0);
-  load_c(m0, n0);
-  const double* Ap = &As[(wm * 32 + fr) * GEMM_LDT + 2 * fk];
-  const double* Bp = &Bs[(wn * 32 + fr) * GEMM_LDT + 2 * fk];
-  v4d acc[TM][TN];
-  for (; t < ntiles; t += gridDim.x) {
-    const int64_t tn = t + gridDim.x;
-    const bool has_next = tn < ntiles;
-    if (has_next) decode(tn, m1, n1);
-    for (int c = 0; c < nchunks; ++c) {
-#pragma unroll
-      for (int it = 0; it < NA; ++it) {
-        const int q = tid + it * 256;
-        *reinterpret_cast<v2d*>(&As[(q >> 4) * GEMM_LDT + 2 * (q & 15)]) = ra[it];
-      }
-#pragma unroll
-      for (int it = 0; it < NBc; ++it) {
-        const int q = tid + it * 256;
-        *reinterpret_cast<v2d*>(&Bs[(q >> 4) * GEMM_LDT + 2 * (q & 15)]) = rb[it];
-      }
-      __syncthreads();
-      if (c + 1 < nchunks) load_chunk(m0, n0, (int64_t)(c + 1) * GEMM_BK);
-      else if (has_next) load_chunk(m1, n1, 0);
-      if (c == 0) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = cscale * cnext[i][j];
-      }
-      if (c == 1 && has_next) load_c(m1, n1);   // cnext is free again from chunk 0 on
-#pragma unroll
-      for (int s = 0; s < GEMM_BK / 8; ++s) {
-        v2d a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const v2d*>(Ap + i * 16 * GEMM_LDT + 8 * s);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const v2d*>(Bp + j * 16 * GEMM_LDT + 8 * s);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        double* cp = g.C + (m0 + wm * 32 + i * 16 + fk) * g.ldc + n0 + wn * 32 + j * 16 + fr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cp[(int64_t)(4 * r) * g.ldc] = g.alpha * acc[i][j][r];
-      }
-    m0 = m1; n0 = n1;
-  }
-}
-
 // (A streaming variant -- 768 resident workgroups taking tiles from a device counter, the next tile's first operand
 // chunk requested during the last chunk of the current one so that only a workgroup's first tile starts cold -- was
-// written and measured: 41.9 vs 46.1 TFLOP/s at M=4736 N=3712 K=128, 1.91 vs 1.76 ms per N = 4096 step.  Like the
-// tile-pipelined kernel below and the 128x128 tiles, it loses to plain one-tile workgroups: the hardware dispatcher
+// written and measured: 41.9 vs 46.1 TFLOP/s at M=4736 N=3712 K=128, 1.91 vs 1.76 ms per N = 4096 step.  Like a
+// tile-pipelined persistent kernel (removed in round 2) and the 128x128 tiles, it loses to plain one-tile workgroups: the hardware dispatcher
 // de-correlates the phases of the three workgroups of a CU, resident workgroups stay in lock-step.  Removed.)
 // (A K = 128 specialisation with every global load of the tile in flight at once -- both K-halves and the C tile requested up
 // front, the halves through a 69.6 KB LDS image one after the other, three barriers per tile instead of eight, two
@@ -570,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
   if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
+  batch_offset(g);
   onepass_body<K>(g, m0, n0, As, Bs);
 }
 
@@ -587,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void chain_band_kernel(GemmArgs gz, GemmArg
   __shared__ __attribute__((aligned(16))) double As[32 * (K / 2 + 4)];
   __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+  batch_offset(gz); batch_offset(gs); batch_offset(gu);
   if (gz.K > 0 && n0 <= m0) {
     onepass_body<K>(gz, m0, n0, As, Bs);
     __syncthreads();   // the LDS image is reused by phase 1
@@ -602,7 +449,8 @@ static void fill_args(GemmArgs& g, const GemmLaunch& L) {
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   g.a_upper_tri = L.a_upper_tri;
-  g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
+  g.map_S = 0; g.map_ntj = 0;
+  g.sA = L.sA; g.sB = L.sB; g.sC = L.sC; g.s_flag = L.s_flag; g.s_info = L.s_info;
   g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
   g.tl_id = -1;
 }
@@ -627,18 +475,12 @@ int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch* Z, const G
 #ifdef GPX_TIMELINE
   gs.tl_id = g_tl_launch++; gu.tl_id = g_tl_launch++;
 #endif
-  dim3 grid((unsigned)(nb / 32), (unsigned)(nb / 32));
+  if (S.batch != U.batch || (Z && Z->batch != S.batch)) { gpx_set_error(h, "chain_band: batch mismatch"); return GPX_ERR_ARG; }
+  dim3 grid((unsigned)(nb / 32), (unsigned)(nb / 32), (unsigned)S.batch);
   if (nb == 128) hipExtLaunchKernelGGL((chain_band_kernel<128>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gz, gs, gu);
   else hipExtLaunchKernelGGL((chain_band_kernel<64>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gz, gs, gu);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
-}
-
-// GPX_TILE_MAP: 0 (default) 1-D row-major enumeration of the lower trapezoid, 1 XCD-aware super-tiles, 2 plain 2-D grid
-static int gemm_tile_map_mode() {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("GPX_TILE_MAP"); on = e ? atoi(e) : 0; }
-  return on;
 }
 
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
@@ -650,13 +492,7 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     return GPX_ERR_ARG;
   }
   GemmArgs g;
-  g.A = L.A; g.B = L.B; g.C = L.C; g.lda = L.lda; g.ldb = L.ldb; g.ldc = L.ldc;
-  g.M = L.M; g.N = L.N; g.K = L.K; g.alpha = L.alpha; g.beta = L.beta;
-  g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
-  g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
-  g.a_upper_tri = L.a_upper_tri;
-  g.map_S = 0; g.map_nti = g.map_ntj = g.map_nsj = g.map_nsuper = 0;
-  g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
+  fill_args(g, L);
 #ifdef GPX_TIMELINE
   g.tl_id = g_tl_launch++;
 #else
@@ -666,51 +502,23 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel only");
     return GPX_ERR_ARG;
   }
-  if (L.a_upper_tri && (L.small_tile || L.variant != 0)) {
+  if (L.a_upper_tri && L.small_tile) {
     gpx_set_error(h, "gemm_nt: a_upper_tri is served by the 64x64 kernel only");
     return GPX_ERR_ARG;
   }
-  dim3 grid((unsigned)(L.N / bm), (unsigned)(L.M / bm));
-  // the persistent pipelined kernel serves the lower-trapezoid updates with C accumulation
-  if (!L.small_tile && L.variant == 1 && L.cyc_P <= 1 && L.lower && L.beta != 0.0 && L.row_off == L.col_off && L.M >= L.N && L.K >= 2 * GEMM_BK) {
-    const int64_t ntj = L.N / 64, nti = L.M / 64;
-    const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
-    const int64_t slots = 256 * (GEMM_PERSIST_WAVES > 3 ? GEMM_PERSIST_WAVES : 3);   // CUs x resident workgroups
-    dim3 pg((unsigned)(ntiles < slots ? ntiles : slots));
-    hipLaunchKernelGGL(gemm_nt_persist_kernel, pg, dim3(256), 0, s, g, (int)ntj, ntiles);
-    GPX_HIP_CHECK(h, hipGetLastError());
-    if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
-    return GPX_OK;
-  }
-  if (!L.small_tile && L.variant == 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && gemm_tile_map_mode() == 0) {
+  if (L.batch < 1 || L.batch > 65535) { gpx_set_error(h, "gemm_nt: batch out of range"); return GPX_ERR_ARG; }
+  dim3 grid((unsigned)(L.N / bm), (unsigned)(L.M / bm), (unsigned)L.batch);
+  // lower-trapezoid updates on 64x64 tiles: 1-D row-major enumeration of the tiles (no empty workgroups, and the
+  // round-robin deal of consecutive workgroup ids over the 8 XCDs stays balanced whatever the grid width)
+  if (!L.small_tile && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N) {
     const int64_t nti = L.M / 64, ntj = L.N / 64;
-    g.map_S = -1; g.map_nti = nti; g.map_ntj = ntj;
+    g.map_S = -1; g.map_ntj = ntj;
     const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
-    if (L.beta != 0.0 && L.role == 1) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true, 1>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
-    else if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
-    else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), dim3((unsigned)ntiles), dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    const dim3 tg((unsigned)ntiles, 1u, (unsigned)L.batch);
+    if (L.beta != 0.0 && L.role == 1) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true, 1>), tg, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    else if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), tg, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
+    else hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), tg, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
     GPX_HIP_CHECK(h, hipGetLastError());
-    return GPX_OK;
-  }
-  if (!L.small_tile && L.variant == 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && gemm_tile_map_mode() == 1) {
-    const int64_t nti = L.M / 64, ntj = L.N / 64;
-    int S = 1;
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("GPX_TILE_S"); forced = e ? atoi(e) : 0; }
-    if (forced > 0) S = forced;
-    else for (int cand : {8, 4, 2}) {
-      const int64_t nsj = (ntj + cand - 1) / cand, nsi = (nti + cand - 1) / cand;
-      if (nsj * (nsj + 1) / 2 + (nsi - nsj) * nsj >= 32) { S = cand; break; }
-    }
-    g.map_S = S; g.map_nti = nti; g.map_ntj = ntj;
-    g.map_nsj = (ntj + S - 1) / S;
-    const int64_t nsi = (nti + S - 1) / S;
-    g.map_nsuper = g.map_nsj * (g.map_nsj + 1) / 2 + (nsi - g.map_nsj) * g.map_nsj;
-    const int64_t rounds = (g.map_nsuper + 7) / 8;
-    if (L.beta != 0.0) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), dim3((unsigned)(rounds * 8 * S * S)), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_nt_kernel<64, 64, false>), dim3((unsigned)(rounds * 8 * S * S)), dim3(256), 0, s, g);
-    GPX_HIP_CHECK(h, hipGetLastError());
-    if (L.stop_event) GPX_HIP_CHECK(h, hipEventRecord(L.stop_event, s));
     return GPX_OK;
   }
   hipEvent_t se = L.stop_event, sb = L.start_event;

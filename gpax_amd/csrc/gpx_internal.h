@@ -5,13 +5,7 @@
 #include <hip/hip_ext.h>
 #include <stdint.h>
 
-#include <atomic>
-#include <condition_variable>
-#include <functional>
-#include <map>
 #include <mutex>
-#include <set>
-#include <thread>
 #include <string>
 #include <utility>
 #include <vector>
@@ -65,13 +59,18 @@ struct GramLaunch {
   int* zero_info = nullptr;  // device int cleared by the launch
   unsigned* zero_flags = nullptr; int n_zero_flags = 0;   // device flag words cleared by the launch
   hipEvent_t start_event = nullptr, stop_event = nullptr;   // the kernel's own dispatch timestamps (profiling)
+  // batched hyper-parameter draws (blockIdx.z = draw): per-draw strides, in elements of the pointer they apply to.
+  // x1 / x2 are shared by the draws; hyp and dev_scalars move together (dev_scalars = hyp + 2 d).
+  int batch = 1;
+  int64_t s_out = 0, s_hyp = 0, s_noise = 0, s_info = 0, s_flags = 0;
 };
 int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& g);
 // one-block-column problems: [K ; identity padding ; k_cross ; r ; zero rows] in ONE launch (same bits as the separate launches)
 int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* xnew, const double* hyp,
                        const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
                        int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
-                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0 = -1, double* zero2 = nullptr, double* r_copy = nullptr);
+                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0 = -1, double* zero2 = nullptr, double* r_copy = nullptr,
+                       int batch = 1, int64_t s_out = 0, int64_t s_hyp = 0, int64_t s_noise = 0, int64_t s_r = 0, int64_t s_info = 0);
 
 // C[M,N] = beta*C + alpha * A[M,K] * B[N,K]^T   (all row-major; K contiguous in A and B)
 struct GemmLaunch {
@@ -85,7 +84,6 @@ struct GemmLaunch {
   int b_lower_tri;      // B is lower triangular (B[n][k] = 0 for k > n): skip dead K
   int small_tile;       // 1: 32x32 workgroup tiles (latency path), 0: 64x64 (throughput path)
   int role = 0;         // 64x64 path: 1 = look-ahead / near-block launch (a separately named instantiation of the same kernel)
-  int variant = 0;      // 64x64 path: 0 = one workgroup per tile, 1 = persistent tile-pipelined kernel
   int cyc_P = 1, cyc_r = 0, cyc_nb = 128;   // block-cyclic local->global row map for the `lower` test (distributed path)
   int a_upper_tri = 0;  // A[m][k] = 0 for k < m: skip the dead K range below each tile's first row (64x64 path)
   // completion event attached to the kernel's own dispatch (hipExtLaunchKernelGGL stopEvent): no separate
@@ -99,20 +97,30 @@ struct GemmLaunch {
   // still running publishes its output with write-through stores and then raises the flag)
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;
   int* wait_info = nullptr;   // device int set to -7 if the bounded wait gives up
+  // batched hyper-parameter draws (blockIdx.z = draw): per-draw strides in elements (doubles for A/B/C, unsigned for the
+  // flags, int for wait_info); 0 = shared by the draws
+  int batch = 1;
+  int64_t sA = 0, sB = 0, sC = 0, s_flag = 0, s_info = 0;
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
-// every diagonal block of a factorisation in ONE launch (block k waits for flagsU[k-1] >= n_signal, raises flagsW[k]) and the
-// one-wave relay that lets a stream wait for such a flag
-int launch_potrf_chain(gpx_handle* h, hipStream_t s, int nb, const double* A0, int64_t lda, double* L0, int64_t ldl, double* W0,
-                       int* info, int nblk, const unsigned* flagsU, unsigned n_signal, unsigned* flagsW);
-int launch_flag_relay(gpx_handle* h, hipStream_t s, const unsigned* flag, unsigned count, int* info);
 // the chain's two band kernels in one launch; Z (optional): an update of the same diagonal block applied first, before the wait for W_k
 int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch* Z, const GemmLaunch& S, const GemmLaunch& U);
 
 // Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
-int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda,
-                      double* L, int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event = nullptr,
-                      const unsigned* wait_flag = nullptr, unsigned wait_count = 0, unsigned* done_flag = nullptr);
+struct PotrfLaunch {
+  int nb;
+  const double* A; int64_t lda;
+  double* L; int64_t ldl;
+  double* W;
+  int* info; int col0;
+  hipEvent_t stop_event = nullptr;
+  const unsigned* wait_flag = nullptr; unsigned wait_count = 0;   // resident start: sleep until *wait_flag >= wait_count
+  unsigned* done_flag = nullptr;                                   // raised behind the last store of W
+  unsigned long long wait_ticks = 25000000ull;                     // bound of the resident wait (100 MHz ticks: 0.25 s)
+  int batch = 1;                                                   // blockIdx.x = draw
+  int64_t sA = 0, sL = 0, sW = 0, s_info = 0, s_flag = 0;
+};
+int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& p);
 
 // y[0:ncols) = beta*y + alpha * x[0:nrows)^T A[0:nrows, 0:ncols)
 int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, int nrows, int64_t ncols,
@@ -120,14 +128,14 @@ int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, in
 
 // fill helpers
 int launch_fill_rect(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t r0, int64_t r1,
-                     int64_t c0, int64_t c1, double diag);
+                     int64_t c0, int64_t c1, double diag, int batch = 1, int64_t sA = 0);
 int launch_fill_identity_pad(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t n,
-                             int64_t npad, int64_t rows_total);
+                             int64_t npad, int64_t rows_total, int batch = 1, int64_t sA = 0);
 int launch_set_row(gpx_handle* h, hipStream_t s, double* dst, const double* src, int64_t n,
                    int64_t npad);
 // one launch: row `r_row` of A <- r (n entries, zero padded to npad; skipped when r_row < 0), rows [z0, z1) <- 0, *info <- 0
 int launch_border_rows(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t npad, int64_t n, int64_t r_row,
-                       const double* r, int64_t z0, int64_t z1, int* info);
+                       const double* r, int64_t z0, int64_t z1, int* info, int batch = 1, int64_t sA = 0, int64_t s_r = 0);
 
 // epilogue reductions
 struct EpilogueLaunch {
@@ -144,6 +152,10 @@ struct EpilogueLaunch {
   double* z_copy = nullptr; int64_t npad = 0;   // also copy z[0:npad) here (the handle's z for later posterior calls)
   // gradient path: alpha = U z (U = L^-T, ld as L, rows n, columns gemv_ncols) computed by extra blocks of the same launch
   const double* gemv_U = nullptr; double* gemv_alpha = nullptr; int64_t gemv_ncols = 0;
+  // batched hyper-parameter draws (blockIdx.y = draw): per-draw strides in doubles.  L, z, vt and gemv_U live in the factor
+  // matrix (s_mat); scal, mean, var and gemv_alpha in the result block (s_out); z_copy, m_new, dev_prior_diag, part on their own
+  int batch = 1;
+  int64_t s_mat = 0, s_out = 0, s_zcopy = 0, s_mnew = 0, s_hyp = 0, s_part = 0;
 };
 int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
 // split epilogue: columns [0, c1) early as partial sums (part: 2 + 2 m doubles), then [c1, n) + part, finalised
@@ -184,66 +196,49 @@ struct DistState {
 };
 void gpx_dist_free(gpx_handle* h);
 
-// A second host thread for enqueueing.  One N = 4096 factorisation is ~350 launch / event calls (~4 us of host
-// time each): issued from one thread the host needs 1.45 ms for a step the GPU finishes in 1.9, i.e. the GPU
-// runs right behind the launcher.  The split-panel schedule therefore issues the chain stream's calls from the
-// caller's thread and the panel / update streams' calls from this worker, ordered by host-side flags wherever
-// one side waits on an event the other records.  The worker spins briefly for the next job before it sleeps.
-struct HostWorker {
-  std::thread th;
-  std::mutex m;
-  std::condition_variable cv;
-  std::function<void()> job;
-  std::atomic<int> state{0};   // 0 idle, 1 job posted, 2 running, 3 exit
-  bool started = false;
-  void start(int device);
-  void post(std::function<void()> f);
-  void wait();
-  void stop();
-};
-
 // ------------------------------------------------------------------------ the handle
 struct StageProf {
   double ms = 0; int64_t launches = 0; double flops = 0, bytes = 0;
 };
 
+// One batch of bordered matrices being factorised (schedule.hip): `batch` independent hyper-parameter draws of the same
+// shape, draw b at base + b * stride.  The GP factor (d_A / d_L / d_W) and the M x M covariance of the sampling path
+// (d_A2 / d_L2 / d_W2) are two such sets.
+struct Mats {
+  double* A = nullptr; double* L = nullptr; double* W = nullptr;
+  int64_t npad = 0, ld = 0, rows_total = 0;
+  int nb = 128, batch = 1;
+  int64_t sA = 0, sW = 0;          // per-draw strides (doubles) of A / L and of W
+};
+
 struct gpx_handle {
   int device = 0;
-  hipStream_t s_main = nullptr, s_trail = nullptr, s_far = nullptr;
-  hipStream_t s_main2 = nullptr;   // second chain stream: consecutive diagonal blocks alternate, so the next potrf_diag can already be resident
-  unsigned* d_flags = nullptr; int64_t flags_cap = 0;
-  bool flags_clean = false;   // the flags were cleared by the gram launch of this call (no memset needed)   // per-step tile counters of the resident start
+  // P (s_main): the chain -- diagonal blocks; P2 (s_main2): the chain's band kernels; Q (s_far): panels and look-ahead
+  // columns; T (s_trail): bulk updates
+  hipStream_t s_main = nullptr, s_trail = nullptr, s_far = nullptr, s_main2 = nullptr;
+  unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per draw: flagsU, flagsW, flagsS (nblk each)
+  bool flags_clean = false;        // the flags were cleared by the gram launch of this call (no memset needed)
   hipEvent_t ev_chain2 = nullptr;
-  const EpilogueLaunch* epi = nullptr;   // set by fit_predict around factor_enqueue: the split-panel loop may launch the early half
+  const EpilogueLaunch* epi = nullptr;   // set by fit_predict around the factorisation: the split-panel loop may launch the early half
   int64_t epi_split_col = 0;             // columns [0, epi_split_col) were reduced early into d_epart (0: not split)
   double* d_epart = nullptr; int64_t epart_cap = 0;
   hipEvent_t ev_build = nullptr;   // K built on the chain stream -> the border rows are built on the panel stream
-  int resident = 2;                // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
-                                   // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag)
   std::string err;
   hipDeviceProp_t prop;
 
-  // options
+  // options (include/gpx.h)
   int nb = 128;
   bool nb_auto = true;   // no explicit "nb" option: 64 for n <= 64 (potrf_diag<64> runs 12 us, <128> 29 us), else 128
-  int lookahead = 1;
-  int depth = 3;       // look-ahead schedule: 1 = classic, 2 = far look-ahead column on a third stream, 3 = split panel (chain stream carries only the diagonal band)
-  int pair_min = 28;   // split-panel schedule: pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
-  int quad_min = 40;   // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
+  int lookahead = 1;     // 0: everything on one stream; 1: the split-panel schedule from split_min_blocks block columns on
+  int resident = 2;      // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
+                         // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag)
+  int pair_min = 28;     // pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
+  int quad_min = 40;     // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
   int split_min_blocks = 3;   // the split-panel (multi-stream) schedule runs from this many block columns; below, one stream
-  int build_small = 1;     // one block column: the whole bordered matrix is built by one launch
-  int potrf_persist = 0;   // in-kernel hand-over schedule: ONE potrf_diag launch for all diagonal blocks (keeps its CU), relay kernels hand W_k to the panel stream.  Measured SLOWER (N=1024 +4 %, 4096 +1.6 %, 16384 +4 %): off
-  int epi_split = 1;   // fit+predict: the posterior / log-marginal reductions over all block columns but the last run on the panel stream beside the last potrf_diag
-  int lp_flag = 1;     // the last border panel waits for the panel stream's last column update through a device counter (0: a stream-level event wait in front of the last potrf_diag)
-  int diag_band = 1;   // fused band kernel, ungrouped steps: panel k-1's update of block (k+1,k+1) is done by the band kernel of step k while it waits for potrf_diag(k)
-  int border_side = 1; // split-panel schedule: k_cross / r / zero border rows are built on the panel stream, off the chain
-  int fuse_band = 1;   // in-kernel hand-over schedule: S = A W_k^T and A -= S S^T in one launch
-  int near_block = 1;  // grouped phases: the next group's columns are updated by Q in a launch of its own, the bulk launch starts behind them
-  int col_split = 0;   // the two look-ahead columns are updated by separate kernels while at least this many block columns are left to the bulk update; 0 = never
-  int la_rows = 3072;  // look-ahead column updates use 64x64 tiles while at least this many rows remain below (-1 % at N = 4096/8192); 0 = never
-  int use_graph = 0;   // 1: replay the fused fit+predict step from a captured hipGraph (measured slower than eager two-stream launches on ROCm 7.2: 2.75 vs 2.48 ms/step)
+  int la_rows = 3072;    // look-ahead column updates use 64x64 tiles while at least this many rows remain below; 0 = never
+  int debug_force_timeout = 0;   // test hook: the next factorisation's first resident wait gives up at once (info = -7)
 
-  // resident inputs
+  // resident inputs (x and x_new are shared by the draws of a batch; r, m_new, hyp, noise are per draw)
   double* d_x = nullptr; int64_t n = 0; int d = 0; int64_t x_cap = 0;
   double* d_xnew = nullptr; int64_t m = 0; int64_t xnew_cap = 0;
   double* d_r = nullptr; int64_t r_cap = 0; bool have_r = false;
@@ -258,6 +253,9 @@ struct gpx_handle {
   int64_t npad = 0, epad = 0, ld = 0;
   int64_t m_in_factor = 0; bool r_in_factor = false;
   bool have_factor = false;
+  // batched draws: number of draws of the current factorisation and their strides (doubles; flags: unsigned)
+  int batch = 1;
+  int64_t s_mat = 0, s_w = 0, s_z = 0, s_r = 0, s_mnew = 0, s_hyp = 0, s_noise = 0, s_out = 0, s_flags = 0, s_mini = 0, s_epart = 0;
 
   // cached hyper-parameters of the factor (for later posterior calls)
   int f_kind = 0; double f_scale = 0, f_jitter = 0;
@@ -283,30 +281,26 @@ struct gpx_handle {
   double* d_A2 = nullptr; int64_t a2_cap = 0;
   double* d_L2 = nullptr; int64_t l2_cap = 0;
   double* d_W2 = nullptr; int64_t w2_cap = 0;
+  double* d_eps = nullptr; int64_t eps_cap = 0;   // standard-normal draws / samples of the sampling path
+  double* d_smp = nullptr; int64_t smp_cap = 0;
 
   // small outputs
   double* d_scal = nullptr;    // [0]=logdet [1]=quad
   int* d_info = nullptr;
   double* d_mean = nullptr; double* d_var = nullptr; int64_t out_cap = 0;  // d_var aliases d_mean + m
   double* h_pinned = nullptr; int64_t pinned_cap = 0;  // pinned staging for small results
-  // All small results live in ONE device block so that one copy brings them to the host:
-  //   d_out = [ scal[8] | info (4 ints) | mean[m] | var[m] ];  d_scal / d_info / d_mean / d_var point into it.
+  // All small results live in ONE device block per draw so that one copy brings them to the host:
+  //   d_out = [ scal[8] | info (4 ints) | mean[m] | var[m] ] x batch (stride s_out);  d_scal / d_info / d_mean / d_var
+  //   point into draw 0's block.
   double* d_out = nullptr;
   // pinned ring for hyper-parameter uploads (a pageable hipMemcpyAsync costs ~28 us of host time on this stack)
   double* h_up = nullptr; int64_t up_slot = 0; int up_next = 0; hipEvent_t up_ev[8] = {}; bool up_used[8] = {};
 
-  // captured hipGraphs of the fused fit+predict step, keyed by shape + buffer addresses
-  std::map<std::string, hipGraphExec_t> graphs;
-  std::set<std::string> graph_warm;
-  bool in_capture = false;   // a stream capture is in progress: enqueue from the caller's thread only
-  int host_threads = 1;      // 2: the side streams are fed by the worker thread (split-panel schedule); 1: one thread
-  HostWorker worker;   // shapes that have run eagerly once (capture starts on the second call)
-
-  // events for the two-stream lookahead
+  // hand-over events of the split-panel schedule
   std::vector<hipEvent_t> ev_panel, ev_trail;
   hipEvent_t ev_join = nullptr, ev_join2 = nullptr;
   std::vector<hipEvent_t> ev_far, ev_w;
-  double* d_mini = nullptr; int64_t mini_cap = 0;   // nb x nb scratch of the split-panel schedule (L_{k+1,k} for the chain)
+  double* d_mini = nullptr; int64_t mini_cap = 0;   // per draw: 2 x (nb x nb) scratch of the split-panel schedule (L_{k+1,k} for the chain)
 
   DistState dist;
 
@@ -317,6 +311,33 @@ struct gpx_handle {
   std::vector<PendingEv> pending;
   std::vector<hipEvent_t> ev_pool;
 };
+
+// the handle's primary factor buffers as a matrix set, with the current batch and strides
+static inline Mats primary_mats(const gpx_handle* h, int64_t rows_total) {
+  Mats M;
+  M.A = h->d_A; M.L = h->d_L; M.W = h->d_W; M.npad = h->npad; M.ld = h->ld; M.rows_total = rows_total;
+  M.nb = h->nb; M.batch = h->batch; M.sA = h->s_mat; M.sW = h->s_w;
+  return M;
+}
+
+// schedule.hip: right-looking blocked Cholesky of every matrix of the set (rows below npad ride along as border rows);
+// tri_base >= 0: the border rows from tri_base on are an identity that is activated block by block (gpx_lml_grad)
+int factor_loop(gpx_handle* h, const Mats& M, int64_t tri_base = -1);
+int ensure_events(gpx_handle* h, size_t nblk, int nb, int batch);
+template <typename T>
+int ensure(gpx_handle* h, T** p, int64_t* cap, int64_t count) {
+  if (count <= *cap && *p) return GPX_OK;
+  if (*p) { (void)hipFree(*p); *p = nullptr; *cap = 0; }
+  if (count <= 0) count = 1;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (size_t)count * sizeof(T));
+  if (e != hipSuccess) {
+    gpx_set_error(h, std::string("hipMalloc failed: ") + hipGetErrorString(e));
+    *p = nullptr;
+    return GPX_ERR_NOMEM;
+  }
+  *cap = count;
+  return GPX_OK;
+}
 
 // profiling helpers (api.hip)
 void prof_begin(gpx_handle* h, hipStream_t s, int stage, double flops, double bytes);

@@ -37,6 +37,7 @@ struct GramArgs {
   int64_t col0;      // global index of x2's first row / out's first column (column slices of one matrix)
   int* zero_info;    // when set, workgroup (0,0) clears it (saves the factorisation a memset launch)
   unsigned* zero_flags; int n_zero_flags;   // likewise: the hand-over flags of the split-panel schedule
+  int64_t s_out, s_hyp, s_noise, s_info, s_flags;   // per-draw strides of a batched launch (blockIdx.z = draw; x1 / x2 are shared)
 };
 
 template <int KIND, bool VEC2>
@@ -49,6 +50,14 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 
   const int tid = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
+  if (blockIdx.z) {   // draw z of a batch: its own hyper-parameters, output matrix, info word and flags
+    const int64_t z = blockIdx.z;
+    g.out += z * g.s_out; g.hyp += z * g.s_hyp;
+    if (g.dev_scalars) g.dev_scalars += z * g.s_hyp;
+    if (g.noise) g.noise += z * g.s_noise;
+    if (g.zero_info) g.zero_info += z * g.s_info;
+    if (g.zero_flags) g.zero_flags += z * g.s_flags;
+  }
   if (blockIdx.x == 0 && blockIdx.y == 0) {
     if (g.zero_info && tid == 0) *g.zero_info = 0;
     if (g.zero_flags) for (int i = tid; i < g.n_zero_flags; i += 256) g.zero_flags[i] = 0u;
@@ -157,7 +166,9 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   g.lower_only = L.lower_only; g.diag_rule = L.diag_rule;
   g.k_scale = L.k_scale; g.noise_scalar = L.noise_scalar; g.jitter = L.jitter;
   g.col0 = L.col0; g.zero_info = L.zero_info; g.zero_flags = L.zero_flags; g.n_zero_flags = L.n_zero_flags;
-  dim3 grid((unsigned)((L.n2 + GT - 1) / GT), (unsigned)((L.n1 + GT - 1) / GT));
+  g.s_out = L.s_out; g.s_hyp = L.s_hyp; g.s_noise = L.s_noise; g.s_info = L.s_info; g.s_flags = L.s_flags;
+  if (L.batch < 1 || L.batch > 65535) { gpx_set_error(h, "gram: batch out of range"); return GPX_ERR_ARG; }
+  dim3 grid((unsigned)((L.n2 + GT - 1) / GT), (unsigned)((L.n1 + GT - 1) / GT), (unsigned)L.batch);
   const bool vec2 = (L.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(L.out) & 15) == 0);
 #define GPX_GRAM_LAUNCH(KIND)                                                        \
   do {                                                                               \
@@ -190,11 +201,21 @@ struct BuildArgs {
   double* r_copy;       // when set: the r row is also written here (r may then live in pinned host memory: no upload in the stream)
   int64_t ident_row0;   // >= 0: rows [ident_row0, ident_row0 + n) are identity rows (the gradient path's border: they become U = L^-T)
   double* zero2;        // when set: a second matrix (same ld) whose rows >= npad are cleared by the same launch (the border of L)
+  int64_t s_out, s_hyp, s_noise, s_r, s_info;   // per-draw strides of a batched launch (blockIdx.y = draw)
 };
 
 template <int KIND>
 __global__ void build_small_kernel(BuildArgs g) {
   const int64_t row = blockIdx.x, col = threadIdx.x;
+  if (blockIdx.y) {
+    const int64_t z = blockIdx.y;
+    g.out += z * g.s_out; g.hyp += z * g.s_hyp; g.dev_scalars += z * g.s_hyp;
+    if (g.noise) g.noise += z * g.s_noise;
+    if (g.r) g.r += z * g.s_r;
+    if (g.r_copy) g.r_copy += z * g.s_r;
+    if (g.zero2) g.zero2 += z * g.s_out;
+    if (g.zero_info) g.zero_info += z * g.s_info;
+  }
   if (blockIdx.x == 0) {
     if (g.zero_info && threadIdx.x == 0) *g.zero_info = 0;
     if (g.zero_flags) for (int i = threadIdx.x; i < g.n_zero_flags; i += blockDim.x) g.zero_flags[i] = 0u;
@@ -241,14 +262,17 @@ __global__ void build_small_kernel(BuildArgs g) {
 int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* xnew, const double* hyp,
                        const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
                        int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
-                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0, double* zero2, double* r_copy) {
+                       unsigned* zero_flags, int n_zero_flags, int64_t ident_row0, double* zero2, double* r_copy, int batch,
+                       int64_t s_out, int64_t s_hyp, int64_t s_noise, int64_t s_r, int64_t s_info) {
   if (npad > 256 || npad <= 0 || !dev_scalars) { gpx_set_error(h, "build_small: at most 256 columns"); return GPX_ERR_ARG; }
   BuildArgs g;
   g.x = x; g.xnew = xnew; g.hyp = hyp; g.dev_scalars = dev_scalars; g.noise = noise; g.r = r; g.out = out; g.ld = ld;
   g.n = n; g.npad = npad; g.m_rows = m_rows; g.r_row = r_row; g.rows_total = rows_total; g.d = d; g.diag_rule = diag_rule;
   g.zero_info = zero_info; g.zero_flags = zero_flags; g.n_zero_flags = n_zero_flags;
   g.ident_row0 = ident_row0; g.zero2 = zero2; g.r_copy = r_copy;
-  const dim3 grid((unsigned)rows_total), block((unsigned)(npad <= 64 ? 64 : (npad <= 128 ? 128 : 256)));
+  g.s_out = s_out; g.s_hyp = s_hyp; g.s_noise = s_noise; g.s_r = s_r; g.s_info = s_info;
+  if (batch > 1 && zero_flags) { gpx_set_error(h, "build_small: zero_flags is not batched"); return GPX_ERR_ARG; }
+  const dim3 grid((unsigned)rows_total, (unsigned)batch), block((unsigned)(npad <= 64 ? 64 : (npad <= 128 ? 128 : 256)));
   switch (kind) {
     case GPX_RBF: hipLaunchKernelGGL((build_small_kernel<GPX_RBF>), grid, block, 0, s, g); break;
     case GPX_MATERN52: hipLaunchKernelGGL((build_small_kernel<GPX_MATERN52>), grid, block, 0, s, g); break;
@@ -263,17 +287,17 @@ int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, 
 
 // out[r][c] = (r == c) ? diag : 0   for r in [r0,r1), c in [c0,c1)
 __global__ void fill_rect_kernel(double* A, int64_t ld, int64_t r0, int64_t r1, int64_t c0,
-                                 int64_t c1, double diag) {
+                                 int64_t c1, double diag, int64_t sA) {
   const int64_t c = c0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t r = r0 + blockIdx.y;
-  if (c < c1 && r < r1) A[r * ld + c] = (r == c) ? diag : 0.0;
+  if (c < c1 && r < r1) A[(int64_t)blockIdx.z * sA + r * ld + c] = (r == c) ? diag : 0.0;
 }
 
 int launch_fill_rect(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t r0, int64_t r1,
-                     int64_t c0, int64_t c1, double diag) {
+                     int64_t c0, int64_t c1, double diag, int batch, int64_t sA) {
   if (r1 <= r0 || c1 <= c0) return GPX_OK;
-  dim3 grid((unsigned)((c1 - c0 + 255) / 256), (unsigned)(r1 - r0));
-  hipLaunchKernelGGL(fill_rect_kernel, grid, dim3(256), 0, s, A, ld, r0, r1, c0, c1, diag);
+  dim3 grid((unsigned)((c1 - c0 + 255) / 256), (unsigned)(r1 - r0), (unsigned)batch);
+  hipLaunchKernelGGL(fill_rect_kernel, grid, dim3(256), 0, s, A, ld, r0, r1, c0, c1, diag, sA);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
@@ -281,9 +305,9 @@ int launch_fill_rect(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_
 // Padding of the (npad x npad) matrix to identity outside the valid (n x n) part:
 // chol([[K,0],[0,I]]) = [[L,0],[0,I]] exactly, so padding never perturbs L.
 int launch_fill_identity_pad(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t n,
-                             int64_t npad, int64_t rows_total) {
-  GPX_RET(launch_fill_rect(h, s, A, ld, 0, rows_total, n, npad, 1.0));  // columns [n,npad) of every row
-  GPX_RET(launch_fill_rect(h, s, A, ld, n, npad, 0, n, 1.0));           // rows [n,npad), columns [0,n)
+                             int64_t npad, int64_t rows_total, int batch, int64_t sA) {
+  GPX_RET(launch_fill_rect(h, s, A, ld, 0, rows_total, n, npad, 1.0, batch, sA));  // columns [n,npad) of every row
+  GPX_RET(launch_fill_rect(h, s, A, ld, n, npad, 0, n, 1.0, batch, sA));           // rows [n,npad), columns [0,n)
   return GPX_OK;
 }
 
@@ -304,9 +328,11 @@ int launch_set_row(gpx_handle* h, hipStream_t s, double* dst, const double* src,
 
 // row r_row <- r, rows [z0, z1) <- 0 (columns [0, n) each), *info <- 0: the per-step border bookkeeping in one launch
 __global__ void border_rows_kernel(double* A, int64_t ld, int64_t npad, int64_t n, int64_t r_row, const double* r,
-                                   int64_t z0, int64_t z1, int* info) {
+                                   int64_t z0, int64_t z1, int* info, int64_t sA, int64_t s_r) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && info) *info = 0;
+  A += (int64_t)blockIdx.z * sA;
+  if (r) r += (int64_t)blockIdx.z * s_r;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0 && info) *info = 0;
   if (c >= n) return;   // columns [n, npad) of every row belong to launch_fill_identity_pad
   if (blockIdx.y == 0) {
     if (r_row >= 0) A[r_row * ld + c] = r ? r[c] : 0.0;
@@ -317,10 +343,10 @@ __global__ void border_rows_kernel(double* A, int64_t ld, int64_t npad, int64_t 
 }
 
 int launch_border_rows(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int64_t npad, int64_t n, int64_t r_row,
-                       const double* r, int64_t z0, int64_t z1, int* info) {
+                       const double* r, int64_t z0, int64_t z1, int* info, int batch, int64_t sA, int64_t s_r) {
   const int64_t nz = z1 > z0 ? z1 - z0 : 0;
-  hipLaunchKernelGGL(border_rows_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)(nz + 1)), dim3(256), 0, s, A, ld,
-                     npad, n, r_row, r, z0, z1, info);
+  hipLaunchKernelGGL(border_rows_kernel, dim3((unsigned)((npad + 255) / 256), (unsigned)(nz + 1), (unsigned)batch), dim3(256), 0, s, A, ld,
+                     npad, n, r_row, r, z0, z1, info, sA, s_r);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

@@ -426,7 +426,7 @@ void tl_set_potrf(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 template <int NB, int NWAVES>
 __device__ __forceinline__ void potrf_block(const double* A, int64_t lda, double* __restrict__ L, int64_t ldl,
                                             double* __restrict__ W, int* info, int col0, const unsigned* wait_flag,
-                                            unsigned wait_count, unsigned* done_flag, double* sm) {
+                                            unsigned wait_count, unsigned* done_flag, unsigned long long wait_ticks, double* sm) {
   constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
   double* Lt = sm;
   double* Wt = sm + NTRI * 256;
@@ -439,14 +439,15 @@ __device__ __forceinline__ void potrf_block(const double* A, int64_t lda, double
   // CU to drain), and sleeps here until the `wait_count` workgroups of the preceding A_kk -= S S^T kernel have
   // published their tiles (write-through stores + an agent-scope counter, gemm.hip).  One lane polls, relaxed;
   // ONE agent-scope acquire after the match drops this CU's stale lines; then the barrier releases the loads.
-  // The spin is bounded (0.25 s of s_memrealtime): on a timeout the block reports info = -7 and carries on.
+  // The spin is bounded (wait_ticks of s_memrealtime, 0.25 s by default): on a timeout the block reports info = -7 and
+  // carries on (the host discards the results and repeats the call with kernel-boundary hand-overs).
   if (wait_flag) {
     POTRF_TL(5, col0);
     if (tid == 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_count) {
         __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) { atomicMin(info, -7); break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) { atomicMin(info, -7); break; }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -594,75 +595,34 @@ __device__ __forceinline__ void potrf_block(const double* A, int64_t lda, double
   }
 }
 
+struct PotrfArgs {
+  const double* A; int64_t lda; double* L; int64_t ldl; double* W; int* info; int col0;
+  const unsigned* wait_flag; unsigned wait_count; unsigned* done_flag; unsigned long long wait_ticks;
+  int64_t sA, sL, sW, s_info, s_flag;   // per-draw strides of a batched launch (blockIdx.x = draw)
+};
+
 template <int NB, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(const double* A, int64_t lda, double* __restrict__ L,
-                                                                 int64_t ldl, double* __restrict__ W, int* info, int col0,
-                                                                 const unsigned* wait_flag, unsigned wait_count,
-                                                                 unsigned* done_flag) {
+__global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(PotrfArgs p) {
   __shared__ double sm[2 * (NB / 16) * (NB / 16 + 1) / 2 * 256 + LEAF_SHARE_DOUBLES];
-  potrf_block<NB, NWAVES>(A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag, sm);
+  const int64_t z = blockIdx.x;
+  potrf_block<NB, NWAVES>(p.A + z * p.sA, p.lda, p.L + z * p.sL, p.ldl, p.W + z * p.sW, p.info + z * p.s_info, p.col0,
+                          p.wait_flag ? p.wait_flag + z * p.s_flag : nullptr, p.wait_count,
+                          p.done_flag ? p.done_flag + z * p.s_flag : nullptr, p.wait_ticks, sm);
 }
 
-// ONE launch for every diagonal block of a factorisation (split-panel schedule with in-kernel hand-overs): the
-// workgroup keeps its CU from the first block to the last.  A potrf_diag launched per block needs a whole CU's LDS
-// each time, and whenever a bulk launch is saturating the chip at that moment it waits the launch out (the
-// dispatcher hands a freed workgroup slot to the bulk kernel's next workgroup, never a whole CU to this one):
-// 20-30 us per block column early in N = 4096, ~2 ms per group of a large factorisation.  Block k waits for the
-// band kernel of step k-1 (flagsU[k-1]) and raises flagsW[k] -- for the band kernel of step k, as before, and for a
-// one-wave relay kernel on the panel stream (below) in place of the per-launch completion event.
-template <int NB, int NWAVES>
-__global__ __launch_bounds__(NWAVES * 64) void potrf_chain_kernel(const double* A0, int64_t lda, double* __restrict__ L0,
-                                                                  int64_t ldl, double* __restrict__ W0, int* info, int nblk,
-                                                                  const unsigned* flagsU, unsigned n_signal, unsigned* flagsW) {
-  __shared__ double sm[2 * (NB / 16) * (NB / 16 + 1) / 2 * 256 + LEAF_SHARE_DOUBLES];
-  for (int k = 0; k < nblk; ++k) {
-    const int64_t c0 = (int64_t)k * NB;
-    potrf_block<NB, NWAVES>(A0 + c0 * lda + c0, lda, L0 + c0 * ldl + c0, ldl, W0 + (int64_t)k * NB * NB, info, (int)c0,
-                            k >= 1 ? flagsU + (k - 1) : nullptr, n_signal, flagsW + k, sm);
-    __syncthreads();   // the LDS image is reused by the next block
-  }
-}
-
-// panel stream: wait (one lane, bounded) until *flag >= count, then exit -- the kernel behind it on the stream starts
-// with W_k visible (its own launch acquires)
-__global__ void flag_relay_kernel(const unsigned* flag, unsigned count, int* info) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < count) {
-      __builtin_amdgcn_s_sleep(4);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) { if (info) atomicMin(info, -7); break; }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-}
-
-int launch_potrf_chain(gpx_handle* h, hipStream_t s, int nb, const double* A0, int64_t lda, double* L0, int64_t ldl, double* W0,
-                       int* info, int nblk, const unsigned* flagsU, unsigned n_signal, unsigned* flagsW) {
-  if (nb == 128)
-    hipLaunchKernelGGL((potrf_chain_kernel<128, POTRF_WAVES_128>), dim3(1), dim3(64 * POTRF_WAVES_128), 0, s, A0, lda, L0, ldl, W0, info,
-                       nblk, flagsU, n_signal, flagsW);
-  else if (nb == 64)
-    hipLaunchKernelGGL((potrf_chain_kernel<64, 4>), dim3(1), dim3(256), 0, s, A0, lda, L0, ldl, W0, info, nblk, flagsU, n_signal, flagsW);
-  else { gpx_set_error(h, "potrf_chain: nb must be 64 or 128"); return GPX_ERR_ARG; }
-  GPX_HIP_CHECK(h, hipGetLastError());
-  return GPX_OK;
-}
-
-int launch_flag_relay(gpx_handle* h, hipStream_t s, const unsigned* flag, unsigned count, int* info) {
-  hipLaunchKernelGGL(flag_relay_kernel, dim3(1), dim3(64), 0, s, flag, count, info);
-  GPX_HIP_CHECK(h, hipGetLastError());
-  return GPX_OK;
-}
-
-int launch_potrf_diag(gpx_handle* h, hipStream_t s, int nb, const double* A, int64_t lda, double* L,
-                      int64_t ldl, double* W, int* info, int col0, hipEvent_t stop_event, const unsigned* wait_flag,
-                      unsigned wait_count, unsigned* done_flag) {
-  switch (nb) {
+int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& q) {
+  PotrfArgs p;
+  p.A = q.A; p.lda = q.lda; p.L = q.L; p.ldl = q.ldl; p.W = q.W; p.info = q.info; p.col0 = q.col0;
+  p.wait_flag = q.wait_flag; p.wait_count = q.wait_count; p.done_flag = q.done_flag; p.wait_ticks = q.wait_ticks;
+  p.sA = q.sA; p.sL = q.sL; p.sW = q.sW; p.s_info = q.s_info; p.s_flag = q.s_flag;
+  if (q.batch < 1) { gpx_set_error(h, "potrf_diag: batch < 1"); return GPX_ERR_ARG; }
+  const dim3 grid((unsigned)q.batch);
+  switch (q.nb) {
     case 64:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), dim3(1), dim3(256), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
       break;
     case 128:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<128, POTRF_WAVES_128>), dim3(1), dim3(64 * POTRF_WAVES_128), 0, s, nullptr, stop_event, 0, A, lda, L, ldl, W, info, col0, wait_flag, wait_count, done_flag);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<128, POTRF_WAVES_128>), grid, dim3(64 * POTRF_WAVES_128), 0, s, nullptr, q.stop_event, 0, p);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

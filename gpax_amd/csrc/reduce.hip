@@ -61,7 +61,18 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
                                                       int64_t vt_ld, const double* m_new, double prior_diag,
                                                       const double* dev_prior_diag, double* mean, double* var,
                                                       int64_t c0, int64_t c1, double* part, int64_t m, int mode,
-                                                      const double* U, double* alpha, int64_t gemv_ncols, int gemv_block0) {
+                                                      const double* U, double* alpha, int64_t gemv_ncols, int gemv_block0,
+                                                      int64_t s_mat, int64_t s_out, int64_t s_zcopy, int64_t s_mnew, int64_t s_hyp,
+                                                      int64_t s_part) {
+  if (blockIdx.y) {   // draw y of a batch
+    const int64_t b = blockIdx.y;
+    L += b * s_mat; if (z) z += b * s_mat; if (vt) vt += b * s_mat; if (U) U += b * s_mat;
+    scal += b * s_out; if (mean) mean += b * s_out; if (var) var += b * s_out; if (alpha) alpha += b * s_out;
+    if (z_copy) z_copy += b * s_zcopy;
+    if (m_new) m_new += b * s_mnew;
+    if (dev_prior_diag) dev_prior_diag += b * s_hyp;
+    if (part) part += b * s_part;
+  }
   if (U && (int)blockIdx.x >= gemv_block0) {
     // gradient path, riding on the same launch: alpha_i = sum_{k >= i} U_ik z_k (U = L^-T, row-major), one wave per row
     const int lane = threadIdx.x & 63;
@@ -111,9 +122,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
 static int launch_epilogue_range(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c0, int64_t c1, double* part, int mode) {
   const int64_t rows = (e.m > 0 && e.z) ? e.m : 0;
   const int64_t gemv_blocks = (e.gemv_U && e.z) ? (e.n + 3) / 4 : 0;
-  hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(rows + 1 + gemv_blocks)), dim3(256), 0, s, e.L, e.ld, e.n, e.z, e.z_copy,
+  hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(rows + 1 + gemv_blocks), (unsigned)e.batch), dim3(256), 0, s, e.L, e.ld, e.n, e.z, e.z_copy,
                      e.z_copy ? e.npad : e.n, e.scal, e.vt, e.vt_ld, e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var,
-                     c0, c1, part, rows, mode, gemv_blocks ? e.gemv_U : nullptr, e.gemv_alpha, e.gemv_ncols, (int)(rows + 1));
+                     c0, c1, part, rows, mode, gemv_blocks ? e.gemv_U : nullptr, e.gemv_alpha, e.gemv_ncols, (int)(rows + 1),
+                     e.s_mat, e.s_out, e.s_zcopy, e.s_mnew, e.s_hyp, e.s_part);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

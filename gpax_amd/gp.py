@@ -19,9 +19,16 @@ Deviations from the reference, on purpose:
 
 from __future__ import annotations
 
+import itertools
 import math
+import zlib
 
 import numpy as np
+
+try:   # 13 us for the (4096, 8) training inputs; the zlib fallback takes 84
+    from xxhash import xxh3_64_intdigest as _digest
+except ImportError:   # pragma: no cover
+    _digest = zlib.adler32
 
 from gpax_amd import _lib, mcmc, state
 from gpax_amd.kernels import Kernel
@@ -34,6 +41,17 @@ Y_STD_DATA_TYPES = DATA_TYPES + (float, int)
 
 
 _PositiveBijection = _Distribution.from_unconstrained   # the default exp bijection (fast_terms assumes it)
+
+_model_uid = itertools.count(1)   # never reused, unlike id(): CPython hands a freed model's id() to the next one
+
+
+def _fingerprint(a):
+    """Content key of an array (shape + a 64-bit digest of its bytes): what decides whether data that is already
+    resident in HBM, or a cached derived array, is still the caller's data -- in-place edits included."""
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a)
+    return (a.shape, a.dtype.str, _digest(a))
 
 
 class GPSample:
@@ -112,7 +130,7 @@ class GaussianProcess:
         if not isinstance(self.mean, Mean):
             raise TypeError("mean must be a gpax_amd.means.Mean")
         self._is_fit = False
-        self._resident = None  # (id of x_transformed) currently resident in HBM
+        self._uid = next(_model_uid)
         self._post_init()
 
     # gpax/gp.py:171-193
@@ -135,8 +153,9 @@ class GaussianProcess:
         pass
 
     def _memo(self, name, key, make):
-        """Per-instance cache of a derived array, keyed by the identity of what it is derived from (x, y and the
-        transforms are fixed after construction, as in the reference; replacing the attribute invalidates the entry)."""
+        """Per-instance cache of a derived array, keyed by the CONTENT of the array it is derived from and the identity
+        of the transform (a Transform is fitted once and immutable afterwards; the model keeps it alive).  Replacing
+        or editing x / y in place invalidates the entry, as the reference's recompute-on-every-call would."""
         memo = self.__dict__.setdefault("_memo_store", {})
         hit = memo.get(name)
         if hit is None or hit[0] != key:
@@ -146,12 +165,12 @@ class GaussianProcess:
 
     @property
     def x_transformed(self):
-        return self._memo("x", (id(self.x), id(self.input_transform)),
+        return self._memo("x", (_fingerprint(self.x), id(self.input_transform)),
                           lambda: self.input_transform.forward(self.x, transforms_as="mean"))
 
     @property
     def y_transformed(self):
-        return self._memo("y", (id(self.y), id(self.output_transform)),
+        return self._memo("y", (_fingerprint(self.y), id(self.output_transform)),
                           lambda: np.atleast_1d(self.output_transform.forward(self.y, transforms_as="mean").squeeze()))
 
     @property
@@ -169,7 +188,9 @@ class GaussianProcess:
         """jax.device_put(x, state.device) of gpax/gp.py:527: once per model."""
         core = self._core()
         x = np.ascontiguousarray(self.x_transformed)
-        key = (id(self), x.shape)
+        # the model's never-reused token + the content of what it would upload (the memo key of x_transformed: raw x and
+        # the transform): a recycled id(), a same-shape successor or an in-place edit can never alias stale device data
+        key = (self._uid, self.__dict__["_memo_store"]["x"][0])
         if getattr(core, "_gp_owner", None) != key:
             core.set_train(x)
             core._gp_owner = key
@@ -261,17 +282,30 @@ class GaussianProcess:
         m_params, k_params, k_noise, k_jitter = self._split(params)
         mean = self.mean(x_new, **m_params)
         noise = k_noise if self.observation_noise else 0.0
-        cov = self.kernel(x_new, x_new, k_noise=noise, k_jitter=k_jitter, **k_params)
+        # cov = kernel(x_new, x_new, k_noise=noise, k_jitter, **k_params) (gpax/gp.py:240-244), built on the device at
+        # the resident x_new (gpx_prior_cov)
+        core = self._core()
+        x_new = np.ascontiguousarray(np.asarray(x_new, dtype=np.float64))
+        if core.d != x_new.shape[1] or core.n == 0:   # no training inputs on this handle (prior-only model): d from x_new
+            core.set_train(x_new[:1])
+            core._gp_owner = core._gp_factor = None
+        self._set_test(core, x_new)
+        prm = _lib.make_params(self.kernel.KIND, k_params["k_scale"], k_params["k_length"], k_params.get("k_period"), None, k_jitter, True)
+        cov = core.prior_cov(prm, float(np.asarray(noise, dtype=np.float64).reshape(-1)[0]))
         return mean, cov
+
+    @staticmethod
+    def _set_test(core, x_new):
+        test_key = (x_new.shape, _digest(x_new))
+        if core._gp_test != test_key:
+            core.set_test(x_new)
+            core._gp_test = test_key
 
     def _posterior(self, x_new, params, want_cov):
         m_params, k_params, k_noise, k_jitter = self._split(params)
         core, x = self._make_train_resident()
         x_new = np.ascontiguousarray(np.asarray(x_new, dtype=np.float64))
-        test_key = (x_new.shape, hash(x_new.tobytes()))
-        if core._gp_test != test_key:
-            core.set_test(x_new)
-            core._gp_test = test_key
+        self._set_test(core, x_new)
         y_std = self.y_std_transformed
         noise_train = y_std**2 if y_std is not None else k_noise  # gpax/gp.py:289-292
         new_noise = float(np.asarray(k_noise).reshape(-1)[0]) if self.observation_noise else 0.0  # :283-286
@@ -336,19 +370,59 @@ class GaussianProcess:
         raise NotImplementedError
 
     def _sample_over_hps(self, rng, x_new, hp, n_hp, condition_on_data):
-        """The vmap over hyper-parameter draws of gpax/gp.py:352-391, as a loop: each draw is a
-        complete gram + factor + posterior on the GPU."""
+        """The vmap over hyper-parameter draws of gpax/gp.py:352-391: a rank's draws run as ONE batched schedule on the
+        GPU (``gpx_sample_batch``: per draw gram + factor + posterior mean / covariance + the M x M factor of the
+        covariance + the MVN draws, every kernel launched once for all draws; covariances stay in HBM), in chunks
+        sized to a memory budget.  With several ranks the draws are dealt round-robin over them."""
         from gpax_amd import parallel
 
         # one independent child stream per draw, so the result does not depend on how the draws
-        # are dealt over the ranks
+        # are dealt over the ranks or chunked
         seeds = rng.integers(0, 2**63 - 1, size=n_hp)
+        x_new = np.ascontiguousarray(np.asarray(x_new, dtype=np.float64))
+        m, gp_n = x_new.shape[0], self.gp_samples
+        consts = self._prior_constants()
 
-        def one(i):
-            p = {k: v[i] for k, v in hp.items()}
-            return self._sample_gp_given_single_hp(np.random.default_rng(seeds[i]), x_new, p, self.gp_samples, condition_on_data)
+        def run(indices):
+            core = self._core()
+            if condition_on_data:
+                core, x = self._make_train_resident()
+                core._gp_factor = None
+                y_std = self.y_std_transformed
+                n = x.shape[0]
+            else:
+                x, y_std, n = None, None, 1
+                if core.d != x_new.shape[1] or core.n == 0:
+                    core.set_train(x_new[:1])
+                    core._gp_owner = core._gp_factor = None
+            self._set_test(core, x_new)
+            # chunk size from a 16 GiB budget: A and L of the bordered factor + the three M x M sampling matrices per draw
+            npad, mpad = -(-n // 128) * 128, -(-m // 128) * 128
+            per_draw = 8 * (2 * (npad + mpad + 64) * npad + 3 * mpad * mpad + 2 * (gp_n + 64) * mpad)
+            chunk = int(max(1, min(64, (16 << 30) // max(per_draw, 1))))
+            mus, sds, ys = [], [], []
+            for c0 in range(0, len(indices), chunk):
+                idx = indices[c0:c0 + chunk]
+                plist, rs, mns, nns, eps = [], [], [], [], []
+                for i in idx:
+                    p = {**consts, **{k: v[i] for k, v in hp.items()}}
+                    m_params, k_params, k_noise, k_jitter = self._split(p)
+                    noise_train = y_std**2 if y_std is not None else k_noise           # gpax/gp.py:289-292
+                    if not condition_on_data:
+                        noise_train = None
+                    plist.append(_lib.make_params(self.kernel.KIND, k_params["k_scale"], k_params["k_length"], k_params.get("k_period"),
+                                                  noise_train, k_jitter, True))
+                    nns.append(float(np.asarray(k_noise).reshape(-1)[0]) if self.observation_noise else 0.0)   # :283-286 / :236-239
+                    if condition_on_data:
+                        rs.append(self.y_transformed - self.mean(x, **m_params))
+                    mns.append(np.broadcast_to(self.mean(x_new, **m_params), (m,)))
+                    eps.append(np.random.default_rng(seeds[i]).standard_normal((gp_n, m)))
+                _, mu, sd, y = core.sample_batch(plist, np.stack(rs) if rs else None, np.stack(mns), np.asarray(nns), np.stack(eps),
+                                                 conditioned=condition_on_data)
+                mus.append(mu); sds.append(sd); ys.append(y)
+            return np.concatenate(mus), np.concatenate(sds), np.concatenate(ys)
 
-        mu, sd, ys = parallel.map_draws(one, n_hp)
+        mu, sd, ys = parallel.map_draws_batched(run, n_hp)
         return hp, mu, sd, ys
 
     # the reference's private sampling entry points (gpax/gp.py:352-397), same names and return values

@@ -78,3 +78,19 @@ def map_draws(fn, n_items, group=None):
         dist.all_gather_object(counts, n_out, group=group)
         n_out = next(c for c in counts if c is not None)
     return tuple(gather_draws([m[k] for m in mine], n_items, group) for k in range(n_out))
+
+
+def map_draws_batched(fn_batch, n_items, group=None):
+    """Like ``map_draws`` for a function that takes ALL of a rank's draw indices at once (the HIP path runs them as one
+    batched schedule, ``gpx_sample_batch``) and returns a tuple of arrays stacked over those draws."""
+    rank, ws = world()
+    idx = partition_draws(n_items, rank, ws)
+    outs = fn_batch(idx) if idx else None
+    n_out = len(outs) if outs is not None else None
+    if ws > 1:
+        import torch.distributed as dist
+
+        counts = [None] * ws
+        dist.all_gather_object(counts, n_out, group=group)
+        n_out = next(c for c in counts if c is not None)
+    return tuple(gather_draws(list(outs[k]) if outs is not None else [], n_items, group) for k in range(n_out))

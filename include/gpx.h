@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GPX_ABI_VERSION 1
+#define GPX_ABI_VERSION 2
 
 /* kernel kinds: gpax/kernels.py:110 (RBFKernel), :129 (MaternKernel nu=5/2), :150 (PeriodicKernel) */
 #define GPX_RBF 0
@@ -39,6 +39,9 @@ extern "C" {
 #define GPX_ERR_NOMEM (-4)
 #define GPX_ERR_COMM (-5)        /* RCCL error */
 #define GPX_ERR_UNSUPPORTED (-6)
+#define GPX_ERR_RETRY (-7)       /* an in-kernel hand-over timed out; the handle has switched to kernel-boundary hand-overs:
+                                    repeat the call (the synchronous entry points do so themselves; of the asynchronous
+                                    pair, gpx_fetch_results returns it) */
 
 typedef struct gpx_handle gpx_handle;
 
@@ -152,6 +155,32 @@ int gpx_set_targets(gpx_handle* h, const double* y_minus_m, const double* m_new)
 int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, double new_noise);
 int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, double* var_out);
 
+/* jax.vmap over hyper-parameter draws (gpax/gp.py:354-364, 384-390) for the fused step: `batch` draws of the hyper-
+ * parameters in ONE schedule -- one bordered matrix per draw, every kernel launched once for all draws (draw index in the
+ * grid), one result block.  params[batch]; y_minus_m (batch, n); m_new (batch, m) or NULL; new_noise[batch] or NULL;
+ * outputs logp[batch], mean_out / var_out (batch, m), info_out[batch] (each optional).  All draws share the kernel kind,
+ * apply_noise and the form of k_noise (scalar or per-point vector).  A draw's results carry the same bits as a
+ * gpx_fit_predict call with its parameters.  Returns the largest info (> 0: that draw's outputs are NaN).  Does not leave
+ * a cached factor behind. */
+int gpx_fit_predict_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* params, const double* y_minus_m,
+                          const double* m_new, const double* new_noise, double* logp, double* mean_out, double* var_out,
+                          int32_t* info_out);
+
+/* _sample_gp_given_single_hp under the vmap of _sample_prior / _sample_posterior (gpax/gp.py:314-338, 352-365, 382-391) for
+ * `batch` hyper-parameter draws in one schedule, device-resident: per draw the posterior (conditioned != 0, gpax/gp.py:247-312
+ * Cholesky branch) or prior (conditioned == 0, gpax/gp.py:212-245) mean and covariance at the resident x_new, sd =
+ * sqrt(diag cov), and nsamp draws  mean + eps chol(cov)^T  (eps (batch, nsamp, m) standard-normal draws from the caller).
+ * The (m, m) covariances and their factors never leave HBM.  Outputs: mean_out / sd_out (batch, m) (optional),
+ * samples_out (batch, nsamp, m), info_out[batch] (optional). */
+int gpx_sample_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* params, const double* y_minus_m,
+                     const double* m_new, const double* new_noise, const double* eps, int64_t nsamp, int32_t conditioned,
+                     double* mean_out, double* sd_out, double* samples_out, int32_t* info_out);
+
+/* "built=<HIP_VERSION> runtime=<hipRuntimeGetVersion()> path=<shared object the HIP runtime was loaded from>".  Returns
+ * GPX_ERR_UNSUPPORTED when the runtime the process resolved is not the major.minor this library was compiled against
+ * (e.g. PyTorch's bundled libamdhip64 imported first), GPX_OK otherwise. */
+int gpx_runtime_info(char* buf, int len);
+
 /* ---- measurement hooks (bench.py; HIP events on the library's own streams) ---- */
 #define GPX_STAGE_GRAM 0        /* gram build of K (n x n) */
 #define GPX_STAGE_GRAM_CROSS 1  /* gram build of k_cross (m x n) */
@@ -175,37 +204,16 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
 
 /* ---- tuning knobs (ints; unknown names -> GPX_ERR_ARG).  Defaults are the measured best on MI355X:
  *   "nb"           panel width, 64 | 128, or 0 = automatic: 64 for n <= 64, else 128 (0)
- *   "lookahead"    0 = everything on one stream, 1 = multi-stream schedules (1)
- *   "depth"        1 | 2 = classic look-ahead on two / three streams, 3 = split-panel schedule (3)
+ *   "lookahead"    0 = everything on one stream, 1 = the split-panel schedule on four streams (1)
  *   "resident"     split-panel schedule: 0 = the chain's kernels hand over at kernel boundaries, 1 = potrf_diag starts
- *                  resident and sleeps on a device flag, 2 = so does S = A W_k^T (2; falls back to 0 under
- *                  hardware-counter collection, inside a stream capture and under per-launch bracketing)
+ *                  resident and sleeps on a device flag, 2 = so does the band kernel S = A W_k^T, A -= S S^T (2; falls back
+ *                  to 0 under hardware-counter collection, under per-launch bracketing, and for good once a wait timed out)
  *   "pair_min" / "quad_min"  group the bulk updates two / four panels at a time while more than this many block
  *                  columns remain; 0 = never (28 / 40)
- *   "diag_band"    fused band kernel, ungrouped steps: the previous panel's update of the diagonal block is done by the band kernel
- *                  itself while it waits for potrf_diag; the panel stream's update of column k+2 starts below that block (1)
- *   "split_min_blocks" the split-panel (three-stream) schedule runs from this many block columns; below, one stream (3)
- *   "build_small"  one or two block columns on one stream (npad <= 256): the whole bordered matrix -- K, identity padding, k_cross, r, identity / zero
- *                  border rows, the cleared border of L -- is built by ONE launch instead of five to nine (1)
- *   "potrf_persist" ONE potrf_diag launch for all diagonal blocks of a factorisation (the workgroup keeps its CU; one-wave relay
- *                  kernels hand W_k to the panel stream).  Measured slower than one launch per block (0)
- *   "epi_split"    fit+predict: the posterior / log-marginal reductions over all block columns but the last are taken on the
- *                  panel stream as soon as those columns are final (beside the last potrf_diag); the epilogue behind the last
- *                  panel only adds the last block column (1)
- *   "lp_flag"      the last border panel waits for the panel stream's last column update through a device counter instead
- *                  of a stream-level event wait in front of the last potrf_diag (1)
- *   "border_side"  split-panel schedule: the border (k_cross rows, r row) is built on the panel stream, whose first kernel is its
- *                  first reader, instead of on the chain stream in front of potrf_diag(0) (1)
- *   "fuse_band"    in-kernel hand-over schedule: the chain's two band kernels (S = A W_k^T, A -= S S^T) run as ONE launch
- *                  whose second phase waits on a device counter for the first phase's tiles (1)
- *   "near_block"   grouped phases: at a group end the next group's block columns are updated by the panel stream in a
- *                  launch of its own and the bulk launch starts behind them, so the next group's chain runs while the bulk
- *                  launch does (1)
+ *   "split_min_blocks" the split-panel schedule runs from this many block columns; below, one stream (3)
  *   "la_rows"      look-ahead column updates run on 64x64 tiles while at least this many rows remain below them; 0 = never (3072)
- *   "col_split"    the two look-ahead columns are updated by separate kernels (only column k+2 behind the wait for the
- *                  bulk update) while at least this many block columns are left to the bulk update; 0 = never (0)
- *   "host_threads" 2 = the panel / bulk streams are fed by a second host thread (1)
- *   "graph"        1 = replay the fused step from a captured hipGraph (0: measured slower on ROCm 7.2) */
+ *   "debug_force_timeout"  test hook: 1 = the first in-kernel wait of the next factorisation gives up at once, so the
+ *                  GPX_ERR_RETRY path (kernel-boundary hand-overs, repeated call) can be exercised; clears itself (0) */
 int gpx_set_option(gpx_handle* h, const char* name, int64_t value);
 int gpx_get_option(gpx_handle* h, const char* name, int64_t* value);
 

@@ -29,7 +29,7 @@ def test_header_symbols_exported():
     for name in names:
         assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert lib.gpx_abi_version() == 1
+    assert lib.gpx_abi_version() == 2
 
 
 def test_struct_layout_matches_header():

@@ -79,20 +79,18 @@ def test_factor_lml_posterior_match_golden(core, name, nb):
     assert np.abs(var - np.diag(g["post_cov"])).max() <= TOL_POST
 
 
-@pytest.mark.parametrize("lookahead", [0, 1, 2, 3])
+@pytest.mark.parametrize("lookahead", [0, 1])
 @pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_fused_fit_predict_matches_golden(core, name, lookahead):
-    """lookahead 0: one stream; 1: classic look-ahead (two streams); 2: depth-2 (three streams); 3: split panel
-    (the default: the chain stream carries only the diagonal band)."""
+    """lookahead 0: everything on one stream; 1: the split-panel schedule (the default: the chain stream carries only
+    the diagonal band)."""
     g = load_golden(name)
     core.set_option("nb", 0)   # automatic again
-    core.set_option("lookahead", 1 if lookahead else 0)
-    core.set_option("depth", max(lookahead, 1))
+    core.set_option("lookahead", lookahead)
     core.set_train(g["x"])
     core.set_test(g["x_new"])
     info, logp, mean, var = core.fit_predict(_params(g), g["y"] - g["m_train"], g["m_new"], _new_noise(g))
     core.set_option("lookahead", 1)
-    core.set_option("depth", 3)
     assert info == 0
     assert abs(logp - float(g["logp"])) <= TOL_LOGP_REL * abs(float(g["logp"]))
     scale = max(1.0, np.abs(g["post_mean"]).max())
@@ -101,40 +99,6 @@ def test_fused_fit_predict_matches_golden(core, name, lookahead):
     # the fused call leaves a cached factor: the separate posterior must agree with it
     info, mean2, var2, _ = core.posterior(g["m_new"], _new_noise(g))
     assert np.abs(mean2 - mean).max() <= 1e-10 * scale and np.abs(var2 - var).max() <= 1e-10
-
-
-def test_graph_replay_tracks_hyperparameters(core):
-    """The fused step is replayed from ONE captured hipGraph per shape; hyper-parameter values
-    live in device memory.  Replays with changing values must match the eager path and the oracle."""
-    import gpax_amd
-    from oracle import gp_oracle as orc
-
-    x, y, xn, p = orc.synthetic_problem(300, 4, 21, seed=11)
-    core.set_option("nb", 0)   # automatic again
-    core.set_train(x)
-    core.set_test(xn)
-    for graph in (1, 0, 1):
-        core.set_option("graph", graph)
-        for scale, ell, noise in [(1.0, 1.0, 0.0067), (2.5, 0.6, 0.02), (0.7, np.array([0.5, 1.0, 1.5, 2.0]), 0.001)]:
-            q = dict(p, k_scale=np.array([scale]), k_length=np.atleast_1d(ell), k_noise=np.array([noise]))
-            prm = gpax_amd.make_params(0, q["k_scale"], q["k_length"], None, q["k_noise"], q["k_jitter"])
-            info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(21), noise)
-            logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, q, observation_noise=True)
-            assert info == 0
-            assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
-            assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
-    # a size with bulk updates on the third stream, replayed twice
-    x, y, xn, p = orc.synthetic_problem(1100, 3, 40, seed=12)
-    core.set_train(x)
-    core.set_test(xn)
-    core.set_option("graph", 1)
-    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
-    logp_ref, mean_ref, var_ref = orc.fit_predict(0, x, y, xn, p)
-    for _ in range(2):
-        info, logp, mean, var = core.fit_predict(prm, y - 1.0, np.ones(40), 0.0)
-        assert info == 0 and abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
-        assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
-    core.set_option("graph", 0)
 
 
 def test_gram_edge_shapes(core):
@@ -188,11 +152,10 @@ def test_against_oracle_seeded(core, n, d, kind):
     assert np.abs(l - orc.cholesky_lower(k_ref)).max() <= TOL_L
 
 
-@pytest.mark.parametrize("depth", [1, 2, 3])
-def test_lookahead_schedules_are_deterministic(core, depth):
-    """No tile is ever updated by two streams at once: repeated runs of the multi-stream schedules
-    at N=2000 (16 panels, ragged) are bit-identical, and agree with the one-stream schedule and the
-    oracle to rounding (the schedules differ in which GEMM variant updates a column block, so not bitwise)."""
+def test_split_schedule_is_deterministic(core):
+    """No tile is ever updated by two streams at once: repeated runs of the split-panel schedule at N=2000
+    (16 panels, ragged) are bit-identical, and agree with the one-stream schedule and the oracle to rounding
+    (the schedules differ in which GEMM variant updates a column block, so not bitwise)."""
     import gpax_amd
     from oracle import gp_oracle as orc
 
@@ -203,24 +166,21 @@ def test_lookahead_schedules_are_deterministic(core, depth):
     core.set_option("lookahead", 0)
     _, _, l_ref = core.fit_factor(prm, want_l=True)
     core.set_option("lookahead", 1)
-    core.set_option("depth", depth)
     _, _, l0 = core.fit_factor(prm, want_l=True)
     for _ in range(4):
         _, _, l = core.fit_factor(prm, want_l=True)
         assert np.array_equal(l, l0)
-    core.set_option("depth", 3)
     assert np.abs(l0 - l_ref).max() <= 1e-12
     assert np.abs(l0 - orc.cholesky_lower(orc.rbf(x, x, 1.0, 1.0, p["k_noise"], 1e-6))).max() <= TOL_L
 
 
-@pytest.mark.parametrize("off", [(), ("fuse_band",), ("diag_band",), ("lp_flag",), ("border_side",), ("near_block",),
-                                 ("fuse_band", "lp_flag", "border_side", "near_block"), ("resident",)])
+@pytest.mark.parametrize("resident", [2, 1, 0])
 @pytest.mark.parametrize("n,m,grouped", [(200, 250, False), (1100, 90, False), (1333, 77, True)])
-def test_schedule_switches_are_bit_identical(core, off, n, m, grouped):
-    """Every hand-over refinement of the split-panel schedule (one launch for the band, the diagonal block in the band
-    kernel, the counter-ordered last panel, the border on the panel stream, the near block of grouped phases, in-kernel
-    hand-overs at all) only moves WHEN a kernel runs: with any of them switched off the factor path must return the very
-    same bits -- and the oracle's numbers."""
+def test_handover_modes_are_bit_identical(core, resident, n, m, grouped):
+    """The in-kernel hand-overs of the split-panel schedule (resident 2: potrf_diag and the fused band kernel start
+    resident and sleep on device flags; 1: potrf_diag only; 0: every hand-over is a kernel boundary, which is also the
+    mode a handle falls back to after a timed-out wait) only move WHEN a kernel runs: all three return the very same
+    bits -- and the oracle's numbers."""
     import gpax_amd
     from oracle import gp_oracle as orc
 
@@ -235,18 +195,12 @@ def test_schedule_switches_are_bit_identical(core, off, n, m, grouped):
     core.set_test(xn)
     try:
         ref = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
-        for name in off:
-            core.set_option(name, 0)
-        if off == ("near_block",):
-            core.set_option("potrf_persist", 1)   # and the one-launch potrf_diag chain (off by default) rides along here
+        core.set_option("resident", resident)
         for _ in range(3):
             got = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
             assert got[0] == ref[0] == 0 and got[1] == ref[1]
             assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
     finally:
-        for name in ("fuse_band", "diag_band", "lp_flag", "border_side", "near_block"):
-            core.set_option(name, 1)
-        core.set_option("potrf_persist", 0)
         core.set_option("split_min_blocks", 3)
         core.set_option("resident", 2)
         core.set_option("nb", 0)
@@ -285,11 +239,11 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
     assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
 
 
-@pytest.mark.parametrize("option,value", [("resident", 0), ("resident", 1), ("host_threads", 2)])
+@pytest.mark.parametrize("option,value", [("resident", 0), ("resident", 1)])
 def test_optional_schedule_features_match_the_default(core, option, value):
     """The in-kernel hand-overs of the chain (default resident = 2: potrf_diag and S = A W_k^T start resident and
-    sleep on flags raised by their producers) against kernel-boundary hand-overs (0) and the half-way mode (1),
-    and the optional second enqueueing host thread: same bits as the default schedule."""
+    sleep on flags raised by their producers) against kernel-boundary hand-overs (0) and the half-way mode (1):
+    same bits as the default schedule, for the factor as well as the fused step."""
     import gpax_amd
     from oracle import gp_oracle as orc
 
@@ -305,7 +259,7 @@ def test_optional_schedule_features_match_the_default(core, option, value):
         info1, logp1, mean1, var1 = core.fit_predict(prm, y - 1.0, np.ones(90), 0.0)
         assert info0 == 0 and info1 == 0
         assert np.array_equal(l0, l1) and logp0 == logp1 and np.array_equal(mean0, mean1) and np.array_equal(var0, var1)
-    core.set_option(option, 2 if option == "resident" else 1)
+    core.set_option(option, 2)
     logp_ref, mean_ref, var_ref = orc.fit_predict(orc.RBF, x, y, xn, p)
     assert abs(logp1 - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
 

@@ -5,6 +5,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 from gpax_amd import _lib
 if sys.argv[1] != "default":
+    os.environ["GPX_LIB_COMPAT"] = "1"
     _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 import gpax_amd
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096

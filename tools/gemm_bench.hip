@@ -23,7 +23,7 @@ int main(int argc, char** argv) {
     t.M = mr; t.N = ncols; t.K = nb; t.alpha = -1.0; t.beta = 1.0; t.lower = 1; t.row_off = r1; t.col_off = r1; t.b_lower_tri = 0;
     const double entries = (double)ncols * (ncols + 1) / 2.0 + (double)(mr - ncols) * ncols;
     for (int variant = 0; variant < 1; ++variant) {
-      t.small_tile = 0; t.variant = variant;
+      t.small_tile = 0;
       for (int w = 0; w < 3; ++w) launch_gemm_nt(nullptr, 0, t);
       CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0)); for (int r = 0; r < 10; ++r) launch_gemm_nt(nullptr, 0, t); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -38,7 +38,7 @@ int main(int argc, char** argv) {
     }
     // panel-solve shape
     GemmLaunch g; g.A = A + r0 * ld + c0; g.lda = ld; g.B = L; g.ldb = nb; g.C = L + r0 * ld + c0; g.ldc = ld;
-    g.M = rows - r0; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 0; g.small_tile = 1; g.variant = 0;
+    g.M = rows - r0; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0; g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 0; g.small_tile = 1;
     for (int w = 0; w < 3; ++w) launch_gemm_nt(nullptr, 0, g);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0)); for (int r = 0; r < 10; ++r) launch_gemm_nt(nullptr, 0, g); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));

@@ -27,7 +27,9 @@ static void run(int nwaves_label) {
   hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst));
   hipMemcpy(dA, a.data(), NB * NB * 8, hipMemcpyHostToDevice);
   hipMemset(dinfo, 0, 4);
-  for (int rep = 0; rep < 3; ++rep) launch_potrf_diag(nullptr, 0, NB, dA, NB, dL, NB, dW, dinfo, 0);
+  PotrfLaunch pl;
+  pl.nb = NB; pl.A = dA; pl.lda = NB; pl.L = dL; pl.ldl = NB; pl.W = dW; pl.info = dinfo; pl.col0 = 0;
+  for (int rep = 0; rep < 3; ++rep) launch_potrf_diag(nullptr, 0, pl);
   hipDeviceSynchronize();
   unsigned long long st[64]; hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost);
   printf("NB=%d: load %llu cycles, first leaf %llu\n", NB, st[1] - st[0], st[2] - st[1]);
