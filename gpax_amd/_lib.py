@@ -82,6 +82,7 @@ SIGNATURES = {
     "gpx_sample_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(KernelParams), _dp, _dp, _dp, _dp, C.c_int64, C.c_int32,
                                    _dp, _dp, _dp, C.POINTER(C.c_int32)]),
     "gpx_runtime_info": (C.c_int, [C.c_char_p, C.c_int]),
+    "gpx_acquisition": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _dp, C.POINTER(C.c_int64), _dp]),
     "gpx_profile_mode": (C.c_int, [C.c_void_p, C.c_int]),
     "gpx_profile_reset": (C.c_int, [C.c_void_p]),
     "gpx_profile_dump": (C.c_int, [C.c_void_p, C.c_char_p]),
@@ -381,6 +382,15 @@ class Core:
             rc = self._lib.gpx_fetch_results(self._h, C.byref(logp), _ptr(mean), _ptr(var))
         info = self._check(rc, "gpx_fetch_results")
         return info, logp.value, mean, var
+
+    def acquisition(self, kind, param, mu_scale=1.0, mu_shift=0.0, sd_scale=1.0, want_values=True):
+        """``gpx_acquisition``: EI (kind 0, param = y_max) or UCB (kind 1, param = beta) over the posterior mean / variance
+        the last ``posterior`` / ``fit_predict`` left on the device.  Returns ``(values or None, argmax, best)``."""
+        vals = np.empty(self.m) if want_values else None
+        idx, best = C.c_int64(), C.c_double()
+        self._check(self._lib.gpx_acquisition(self._h, int(kind), float(param), float(mu_scale), float(mu_shift), float(sd_scale),
+                                              _ptr(vals), C.byref(idx), C.byref(best)), "gpx_acquisition")
+        return vals, idx.value, best.value
 
     # -- batched hyper-parameter draws (gpax's vmap over hp samples, gpax/gp.py:354-364,384-390)
     def fit_predict_batch(self, param_list, y_minus_m, m_new=None, new_noise=None):

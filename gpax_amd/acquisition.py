@@ -1,8 +1,10 @@
 """Acquisition functions (``gpax/acquisition.py``): analytic EI / UCB on the HIP posterior and the
-Halton-sampling optimiser.  The per-candidate arithmetic is O(M) host NumPy as in the reference;
-the posterior it consumes comes from the HIP path, with the factor cached across the candidate
-batches (the reference re-factorises k_train for each of the 100-point batches,
-gpax/acquisition.py:203-210 -> gpax/gp.py:293-304)."""
+Halton-sampling optimiser.  For a conditioned model with ``fast=True`` (the reference's default) the analytic
+values are a device epilogue over the posterior mean / variance that stay in HBM (``gpx_acquisition``), and the
+Halton optimiser evaluates ALL its candidates as the border rows of one factorisation -- the reference pushes them
+through ``predict`` in batches of ``batch_threshold`` = 100, re-factorising k_train each time
+(gpax/acquisition.py:203-210 -> gpax/gp.py:293-304).  The Monte-Carlo path (q > 1) is host NumPy over
+``model.sample`` as in the reference."""
 
 from __future__ import annotations
 
@@ -13,6 +15,8 @@ from scipy.special import ndtr
 from scipy.stats import qmc
 
 from gpax_amd import state
+
+ACQ_EI, ACQ_UCB = 0, 1   # include/gpx.h GPX_ACQ_*
 
 
 def split_array(x, s):
@@ -89,10 +93,28 @@ class AcquisitionFunction:
         l_bounds = np.tile(np.atleast_1d(self.bounds[0, :].squeeze()), self.q)
         u_bounds = np.tile(np.atleast_1d(self.bounds[1, :].squeeze()), self.q)
         samples = qmc.scale(samples, l_bounds, u_bounds).reshape(n_samples, self.q, -1)
+        if self._device_path(model):
+            # all candidates in ONE posterior call (they are independent rows: the values do not depend on the batching,
+            # which the reference needs only to bound jax's memory); values, arg-max and maximum come from the device
+            _, argmax, best = self._device_values(model, samples.reshape(n_samples, -1), want_values=False)
+            return samples[argmax, ...], float(best)
         vals = [np.atleast_1d(self.__call__(model, xx)) for xx in split_array(samples, self.batch_threshold)]
         vals = np.concatenate(vals).flatten()
         argmax = int(vals.argmax())
         return samples[argmax, ...], float(vals[argmax])
+
+    # -- device epilogue (subclasses with an analytic form set DEVICE_KIND and _device_param)
+    DEVICE_KIND = None
+
+    def _device_param(self, model):
+        raise NotImplementedError
+
+    def _device_path(self, model):
+        return (self.DEVICE_KIND is not None and self.q == 1 and not self.force_monte_carlo and self.fast
+                and model.x is not None and model.y is not None)
+
+    def _device_values(self, model, x, want_values=True):
+        return model._acquisition_fast(x, self.DEVICE_KIND, self._device_param(model), want_values)
 
     def optimize(self, model, n, method="halton"):
         if method.lower() == "halton":
@@ -109,7 +131,14 @@ class UpperConfidenceBound(AcquisitionFunction):
             raise ValueError("beta must be >= 0")
         self.beta = beta
 
+    DEVICE_KIND = ACQ_UCB
+
+    def _device_param(self, model):
+        return self.beta
+
     def _analytic(self, model, x):
+        if self._device_path(model):
+            return self._device_values(model, x)[0]
         mu, sd = model.predict(x, fast=self.fast)
         if math.isinf(self.beta):
             return sd
@@ -137,7 +166,14 @@ class ExpectedImprovement(AcquisitionFunction):
         y_max, _ = model.predict(x_star, fast=True)
         return y_max
 
+    DEVICE_KIND = ACQ_EI
+
+    def _device_param(self, model):
+        return float(self._get_y_max(model))
+
     def _analytic(self, model, x):
+        if self._device_path(model):
+            return self._device_values(model, x)[0]
         mu, sd = model.predict(x, fast=self.fast)
         y_max = self._get_y_max(model)
         u = (mu - y_max) / sd

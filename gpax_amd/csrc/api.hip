@@ -317,6 +317,7 @@ static int* option_slot(gpx_handle* h, const char* name) {
   if (!strcmp(name, "quad_min")) return &h->quad_min;
   if (!strcmp(name, "split_min_blocks")) return &h->split_min_blocks;
   if (!strcmp(name, "la_rows")) return &h->la_rows;
+  if (!strcmp(name, "batch_group")) return &h->batch_group;
   if (!strcmp(name, "debug_force_timeout")) return &h->debug_force_timeout;
   return nullptr;
 }
@@ -1018,6 +1019,7 @@ extern "C" int gpx_posterior(gpx_handle* h, const double* m_new, double new_nois
   GPX_RET(check_handover(h, reinterpret_cast<const int*>(blk + 8)[0]));
   if (mean_out) memcpy(mean_out, blk + GPX_OUT_HEAD, (size_t)m * sizeof(double));
   if (var_out) memcpy(var_out, blk + GPX_OUT_HEAD + m, (size_t)m * sizeof(double));
+  h->m_resident = m;
   return reinterpret_cast<const int*>(blk + 8)[0];
 }
 
@@ -1165,6 +1167,7 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
       if (h->pending[i].stage == GPX_STAGE_FACTOR_TOTAL) { (void)hipEventRecord(h->pending[i].b, s); break; }
   }
   factor_commit(h, p, m, true);
+  h->m_resident = m;
   return GPX_OK;
 }
 
@@ -1217,7 +1220,7 @@ static int set_targets_batch(gpx_handle* h, int batch, const double* y_minus_m, 
 // After a batched call the handle's single-draw caches (factor, z, targets) describe draw 0 only in part: drop them.
 static void batch_invalidate(gpx_handle* h) {
   h->have_factor = false; h->have_z = false; h->have_r = false; h->have_mnew = false;
-  h->batch = 1; h->s_r = 0; h->s_mnew = 0; h->s_noise = 0;
+  h->batch = 1; h->s_r = 0; h->s_mnew = 0; h->s_noise = 0; h->m_resident = 0;
 }
 
 static int fit_predict_batch_once(gpx_handle* h, int batch, const gpx_kernel_params* params, const double* y_minus_m,
@@ -1233,7 +1236,7 @@ static int fit_predict_batch_once(gpx_handle* h, int batch, const gpx_kernel_par
   fp.kind = params->kind; fp.apply_noise = params->apply_noise; fp.m_rows = m; fp.with_r = true; fp.want_k = false;
   const int erc = fit_predict_enqueue(h, fp);
   const double* blk = nullptr;
-  int frc = erc == GPX_OK ? fetch_block(h, 0, &blk, batch) : erc;
+  int frc = erc == GPX_OK ? fetch_block(h, 2 * std::max<int64_t>(m, 1), &blk, batch) : erc;
   const int64_t so = h->s_out;
   batch_invalidate(h);
   GPX_RET(frc);
@@ -1371,7 +1374,7 @@ static int sample_batch_once(gpx_handle* h, int batch, const gpx_kernel_params* 
     GPX_HIP_CHECK(h, hipMemcpyAsync(samples_out, h->d_S, (size_t)(nsamp * m * batch) * sizeof(double), hipMemcpyDeviceToHost, s));
   }
   const double* blk = nullptr;
-  const int frc = fetch_block(h, 0, &blk, batch);
+  const int frc = fetch_block(h, 2 * std::max<int64_t>(m, 1), &blk, batch);
   const int64_t so = h->s_out;
   const bool had_mnew = h->have_mnew;
   batch_invalidate(h);
@@ -1408,6 +1411,32 @@ extern "C" int gpx_sample_batch(gpx_handle* h, int32_t batch, const gpx_kernel_p
   return with_retry([&] {
     return sample_batch_once(h, batch, params, y_minus_m, m_new, new_noise, eps, nsamp, conditioned, mean_out, sd_out, samples_out, info_out);
   });
+}
+
+// ------------------------------------------------------------------------------- acquisition
+
+// Analytic acquisition values over the posterior mean / variance that the last gpx_posterior / gpx_fit_predict[_async] left in
+// HBM (gpax/acquisition.py:260-266 UCB, :291-298 EI, evaluated by the reference on the host after model.predict): one
+// launch, the values and their arg-max come back in one copy.  The reference's Halton optimiser pushes 10 000 candidates
+// through predict() in 100 batches of 100 (gpax/acquisition.py:203-210), each re-factorising k_train; here all candidates are
+// the border rows of ONE factorisation and this epilogue.
+extern "C" int gpx_acquisition(gpx_handle* h, int32_t kind, double param, double mu_scale, double mu_shift, double sd_scale,
+                               double* acq_out, int64_t* argmax_out, double* best_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (kind != GPX_ACQ_EI && kind != GPX_ACQ_UCB) { gpx_set_error(h, "gpx_acquisition: kind must be GPX_ACQ_EI or GPX_ACQ_UCB"); return GPX_ERR_ARG; }
+  const int64_t m = h->m_resident;
+  if (m <= 0 || !h->d_out) { gpx_set_error(h, "gpx_acquisition: no posterior mean / variance resident (call gpx_posterior or gpx_fit_predict first)"); return GPX_ERR_STATE; }
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  hipStream_t s = h->s_main;
+  GPX_RET(ensure(h, &h->d_vec, &h->vec_cap, m + 2));
+  GPX_RET(launch_acquisition(h, s, h->d_mean, h->d_mean + m, m, kind, param, mu_scale, mu_shift, sd_scale, h->d_vec, h->d_vec + m));
+  std::vector<double> tail(2);
+  if (acq_out) GPX_HIP_CHECK(h, hipMemcpyAsync(acq_out, h->d_vec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(tail.data(), h->d_vec + m, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPX_HIP_CHECK(h, hipStreamSynchronize(s));
+  if (best_out) *best_out = tail[0];
+  if (argmax_out) *argmax_out = (int64_t)tail[1];
+  return GPX_OK;
 }
 
 // ------------------------------------------------------------------------- runtime identity

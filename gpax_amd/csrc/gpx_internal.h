@@ -162,6 +162,10 @@ int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
 int launch_epilogue_partial(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c1, double* part);
 int launch_epilogue_final(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e, int64_t c0, double* part);
 
+// acquisition epilogue over device-resident (mean, var): EI / UCB values and their arg-max (reduce.hip)
+int launch_acquisition(gpx_handle* h, hipStream_t s, const double* mean, const double* var, int64_t m, int kind, double param,
+                       double mu_scale, double mu_shift, double sd_scale, double* acq, double* best);
+
 // post_reduce only (mean / variance of m rows of V^T against z)
 int launch_post_reduce(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
 
@@ -236,6 +240,7 @@ struct gpx_handle {
   int quad_min = 40;     // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
   int split_min_blocks = 3;   // the split-panel (multi-stream) schedule runs from this many block columns; below, one stream
   int la_rows = 3072;    // look-ahead column updates use 64x64 tiles while at least this many rows remain below; 0 = never
+  int batch_group = 4;   // batches of >= 4 draws: bulk updates grouped g panels at a time throughout (0: the single-draw thresholds)
   int debug_force_timeout = 0;   // test hook: the next factorisation's first resident wait gives up at once (info = -7)
 
   // resident inputs (x and x_new are shared by the draws of a batch; r, m_new, hyp, noise are per draw)
@@ -252,6 +257,7 @@ struct gpx_handle {
   double* d_W = nullptr; int64_t w_cap = 0;     // (npad/nb) blocks of nb*nb: inv(L_kk)
   int64_t npad = 0, epad = 0, ld = 0;
   int64_t m_in_factor = 0; bool r_in_factor = false;
+  int64_t m_resident = 0;          // the result block of draw 0 holds the posterior mean / variance of this many test points
   bool have_factor = false;
   // batched draws: number of draws of the current factorisation and their strides (doubles; flags: unsigned)
   int batch = 1;

@@ -173,3 +173,49 @@ int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, in
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
+
+// ---- acquisition epilogue over the resident (mean, var) of the last posterior (gpax/acquisition.py:260-266, 291-298) ----
+// kind 0: expected improvement  EI = sd * pdf(u) + (mu - y_max) * cdf(u),  u = (mu - y_max) / sd
+// kind 1: upper confidence bound  mu + sqrt(beta + 1e-12) * sd   (beta = inf: sd; beta = 0: mu)
+// mu, sd in RAW units: mu = mean * mu_scale + mu_shift, sd = sqrt(var) * sd_scale (the output transform's reverse,
+// gpax/transforms.py:262-274, 311-317, is affine).  One workgroup; also the arg-max (first index of the largest value).
+__global__ __launch_bounds__(1024) void acquisition_kernel(const double* mean, const double* var, int64_t m, int kind, double param,
+                                                          double mu_scale, double mu_shift, double sd_scale, double* acq,
+                                                          double* best /* [value, index] */) {
+  __shared__ double sv[1024];
+  __shared__ long long si[1024];
+  double bv = -INFINITY; long long bi = -1;
+  for (int64_t i = threadIdx.x; i < m; i += 1024) {
+    const double mu = fma(mean[i], mu_scale, mu_shift), sd = sqrt(var[i]) * sd_scale;
+    double a;
+    if (kind == 0) {
+      const double u = (mu - param) / sd;
+      const double cdf = 0.5 * erfc(-u * 0.70710678118654752440);
+      const double pdf = exp(-0.5 * u * u - 0.91893853320467274178);   // - 0.5 * log(2 pi)
+      a = sd * pdf + (mu - param) * cdf;
+    } else {
+      a = isinf(param) ? sd : (param == 0.0 ? mu : mu + sqrt(param + 1e-12) * sd);
+    }
+    acq[i] = a;
+    if (a > bv || bi < 0) { bv = a; bi = i; }   // strided scan: the first index wins on ties within a thread
+  }
+  sv[threadIdx.x] = bv; si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const double ov = sv[threadIdx.x + o]; const long long oi = si[threadIdx.x + o];
+      if (oi >= 0 && (si[threadIdx.x] < 0 || ov > sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x]))) {
+        sv[threadIdx.x] = ov; si[threadIdx.x] = oi;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { best[0] = sv[0]; best[1] = (double)si[0]; }
+}
+
+int launch_acquisition(gpx_handle* h, hipStream_t s, const double* mean, const double* var, int64_t m, int kind, double param,
+                       double mu_scale, double mu_shift, double sd_scale, double* acq, double* best) {
+  hipLaunchKernelGGL(acquisition_kernel, dim3(1), dim3(1024), 0, s, mean, var, m, kind, param, mu_scale, mu_shift, sd_scale, acq, best);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}

@@ -224,7 +224,12 @@ struct SplitSchedule {
     h = hh; c = make_ctx(h, M, tri_base);
     nb = c.nb; nblk = c.nblk; B = (double)M.batch;
     P = h->s_main; Q = h->s_far; T = h->s_trail;
-    resident = h->resident != 0 && h->prof_mode != 1 && nblk >= 3;
+    // Batched draws hand over at kernel boundaries: a resident consumer holds its CU slots (and LDS) while it sleeps, and its
+    // grid grows with the batch -- 16 band workgroups per draw park 34 KB of LDS each on as many CUs, and from 16 draws on
+    // no CU is left with the 144 KB potrf_diag needs (measured: the wait times out, info = -7); the last panel's waiting
+    // grid (border tiles x draws) can likewise fill every slot its own producer needs.  With several draws in flight the
+    // GPU is throughput-bound anyway; the bits do not depend on the hand-over mode.
+    resident = h->resident != 0 && h->prof_mode != 1 && nblk >= 3 && M.batch == 1;
     P2 = resident ? h->s_main2 : P;
     chain2 = resident && h->resident >= 2;
     fuse_band = chain2;
@@ -232,7 +237,11 @@ struct SplitSchedule {
     // completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL stopEvent) except under
     // per-launch profiling, where they are recorded behind the kernel as usual
     attach = h->prof_mode != 1;
-    use_dib = fuse_band && !kinv;
+    // the diagonal block (k+1,k+1) gets panel k-1 from the chain itself, in EVERY hand-over mode (phase 0 of the fused band
+    // kernel, or a launch of its own in front of the band kernels): the arithmetic -- which tile routine touches which
+    // tile, in which order -- must not depend on the mode, or a batched call (kernel-boundary hand-overs) and a
+    // single-draw call (in-kernel hand-overs) would differ in the last bits
+    use_dib = !kinv;
     n_signal = (unsigned)((nb / 32) * (nb / 32 + 1) / 2);   // lower 32x32 tiles of a diagonal block
     flagsU = h->d_flags;              // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
     flagsW = h->d_flags + nblk;       // [k]: W_k published (S = A W_k^T of step k waits)
@@ -240,6 +249,15 @@ struct SplitSchedule {
     // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
     // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
     pair_min = kinv ? std::min<int64_t>(h->pair_min, 8) : h->pair_min; quad_min = h->quad_min;
+    // Batches of four or more draws are throughput-bound from the first step to the last: the chain's latency hides behind
+    // the other draws' work, so the bulk updates are grouped throughout (K = g nb passes run the bulk kernel at 48-53
+    // instead of 40 TFLOP/s and cut the passes over the trailing matrices g-fold).  Measured at N = 4096, 16 draws:
+    // 40.5 -> 45.7 TFLOP/s aggregate.  The grouping is what a single-draw call does with "pair_min" = g / 4,
+    // "quad_min" = g / 2, bit for bit; "batch_group" = 0 keeps the single-draw thresholds.
+    if (M.batch >= 4 && h->batch_group >= 2 && !kinv) {
+      pair_min = 1;
+      quad_min = h->batch_group >= 4 ? 2 : 0;
+    }
     t_from = nblk;
     dib.assign((size_t)nblk + 2, 0); band_t.assign((size_t)nblk + 2, -1);
     tev.assign((size_t)nblk, nullptr); t_pending.assign((size_t)nblk, 0);
@@ -264,7 +282,7 @@ struct SplitSchedule {
   // counter that update's tiles raise (flagsS[nblk-1], otherwise unused) instead of a stream-level event wait in front
   // of the last potrf_diag, which kept that kernel from starting resident (+17 us at the tail of every step)
   void plan_band() {
-    if (!chain2 || kinv) return;
+    if (kinv) return;
     int64_t lt = -1, ge = -1, ti = -1, tf = nblk;
     for (int64_t j = 0; j < nblk; ++j) {
       if (j > ge) ge = j + group_size(nblk - j) - 1;
@@ -276,7 +294,7 @@ struct SplitSchedule {
         if (gn >= 2) near = std::max<int64_t>(0, std::min<int64_t>(gn, nblk - (j + 3)));
       }
       const int64_t mr = rows - (j + 2) * nb, ncb = std::min<int64_t>(2, nblk - (j + 1));
-      if (j == nblk - 2 && j - lt == 1 && mr > 0 && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) lp_flag = true;
+      if (chain2 && j == nblk - 2 && j - lt == 1 && mr > 0 && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) lp_flag = true;
       if (use_dib && mr > 0 && ncb > 1 && j - lt == 1) {
         dib[(size_t)(j + 1)] = 1;
         band_t[(size_t)(j + 1)] = (ti >= 0 && j + 2 >= tf) ? ti : -1;
@@ -343,20 +361,25 @@ struct SplitSchedule {
     u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
     u.batch = c.M.batch; u.sA = h->s_mini; u.sB = h->s_mini; u.sC = c.M.sA; u.s_flag = h->s_flags; u.s_info = c.s_info;
     if (resident) u.signal = flagsU + k;   // potrf_diag(k+1) is already resident and polls this counter
-    if (fuse_band) {   // both band kernels in one launch: S's tiles are handed over through flagsS[k]
+    GemmLaunch z;   // phase 0: block (k+1,k+1) -= L_{k+1,k-1} L_{k+1,k-1}^T (panel k-1), see dib[] above
+    const bool phase0 = dib[(size_t)k] != 0;
+    if (phase0) {
+      if (band_t[(size_t)k] >= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)band_t[(size_t)k]], 0));   // the bulk launch that last wrote the block
+      z = c.update(r0, nb, k + 1, 1, k - 1, 1, true);
+      z.row_off = 0; z.col_off = 0;
+    }
+    if (fuse_band) {   // both band kernels (and phase 0) in one launch: S's tiles are handed over through flagsS[k]
       g.signal = flagsS + k;
       u.wait_flag = flagsS + k; u.wait_count = (unsigned)((nb / 32) * (nb / 32)); u.wait_info = h->d_info;
-      GemmLaunch z;   // phase 0: block (k+1,k+1) -= L_{k+1,k-1} L_{k+1,k-1}^T (panel k-1), see dib[] above
-      const bool phase0 = dib[(size_t)k] != 0;
-      if (phase0) {
-        if (band_t[(size_t)k] >= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)band_t[(size_t)k]], 0));   // the bulk launch that last wrote the block
-        z = c.update(r0, nb, k + 1, 1, k - 1, 1, true);
-        z.row_off = 0; z.col_off = 0;
-      }
       prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * (phase0 ? 3.0 : 2.0) * (double)nb * nb * nb, B * 8.0 * 6.0 * nb * nb);
       GPX_RET(launch_chain_band(h, PB, phase0 ? &z : nullptr, g, u));
       prof_end(h, PB);
       return GPX_OK;
+    }
+    if (phase0) {
+      prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * (double)nb * nb * nb, B * 8.0 * 3.0 * nb * nb);
+      GPX_RET(launch_gemm_nt(h, PB, z));
+      prof_end(h, PB);
     }
     prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * (double)nb * nb * nb, B * 8.0 * 3.0 * nb * nb);
     GPX_RET(launch_gemm_nt(h, PB, g));
@@ -429,8 +452,10 @@ struct SplitSchedule {
     const int64_t rows = c.rows_at(k), rr = (k + 2 + skip_blocks) * nb, mr = rows - rr;
     if (mr <= 0) return GPX_OK;
     // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
-    // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency
-    GemmLaunch t = c.update(rr, mr, cfirst, ncol, kfirst, npan, !(h->la_rows > 0 && mr >= h->la_rows));
+    // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency.  The choice follows the
+    // STEP (rows below block row k+2), not the launch: a column whose update starts one block lower in one hand-over
+    // mode ("diagonal block in the band kernel") must get the same tile routine -- the same bits -- in every mode.
+    GemmLaunch t = c.update(rr, mr, cfirst, ncol, kfirst, npan, !(h->la_rows > 0 && rows - (k + 2) * nb >= h->la_rows));
     if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
     if (lp_flag && k == nblk - 2 && cfirst == nblk - 1) t.signal = flagsS + (nblk - 1);   // the last border panel waits for these tiles (chain stream)
     t.role = 1;

@@ -487,6 +487,26 @@ class GaussianProcess:
         mu, cov = self._get_mean_and_covariance_unconditioned(x_new, hps)
         return np.broadcast_to(mu, (x_new.shape[0],)), np.sqrt(np.diagonal(cov))
 
+    def _acquisition_fast(self, x_new, kind, param, want_values=True):
+        """``predict(x_new, fast=True)`` (gpax/gp.py:464-501) followed by the analytic acquisition function
+        (gpax/acquisition.py:260-266, 291-298) WITHOUT the round trip: the posterior mean / variance of all candidates
+        stay in HBM and the EI / UCB values and their arg-max are an epilogue over them (``gpx_acquisition``).  The output
+        transform's reverse is affine and is applied inside that epilogue.  Conditioned models only.
+        Returns ``(values or None, argmax, best)``."""
+        x_t = self.input_transform.forward(x_new, transforms_as="mean")
+        _, rng = state.get_rng_key()
+        if not self._is_fit:
+            hps, _ = self._get_hp_samples_from_prior(rng, True)
+        else:
+            hps, _ = self._get_hp_samples_from_posterior(True)
+        hps = {**self._prior_constants(), **{k: v[0] for k, v in hps.items()}}
+        self._posterior(x_t, hps, want_cov=False)        # leaves (mean, var) of every candidate on the device
+        t = self.output_transform
+        shift = float(np.asarray(t.reverse(np.zeros(1), transforms_as="mean")).ravel()[0])
+        mu_scale = float(np.asarray(t.reverse(np.ones(1), transforms_as="mean")).ravel()[0]) - shift
+        sd_scale = float(np.asarray(t.reverse(np.ones(1), transforms_as="std")).ravel()[0])
+        return self._core().acquisition(kind, param, mu_scale, shift, sd_scale, want_values)
+
     def predict(self, x_new, fast=False):
         """gpax/gp.py:486-501."""
         if not fast:

@@ -176,6 +176,19 @@ int gpx_sample_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* para
                      const double* m_new, const double* new_noise, const double* eps, int64_t nsamp, int32_t conditioned,
                      double* mean_out, double* sd_out, double* samples_out, int32_t* info_out);
 
+/* Analytic acquisition functions (gpax/acquisition.py:260-266 UpperConfidenceBound._analytic, :291-298
+ * ExpectedImprovement._analytic) as an epilogue over the posterior mean / variance the last gpx_posterior /
+ * gpx_fit_predict[_async] left in HBM:
+ *   mu = mean * mu_scale + mu_shift,  sd = sqrt(var) * sd_scale     (the output transform's reverse, gpax/gp.py:499-500)
+ *   GPX_ACQ_EI : param = y_max;  u = (mu - y_max) / sd;  sd * pdf(u) + (mu - y_max) * cdf(u)
+ *   GPX_ACQ_UCB: param = beta;   mu + sqrt(beta + 1e-12) * sd  (beta = inf: sd, beta = 0: mu)
+ * acq_out (m) optional; argmax_out / best_out: first index of the largest value and that value (what
+ * _optimize_halton keeps, gpax/acquisition.py:211-216). */
+#define GPX_ACQ_EI 0
+#define GPX_ACQ_UCB 1
+int gpx_acquisition(gpx_handle* h, int32_t kind, double param, double mu_scale, double mu_shift, double sd_scale,
+                    double* acq_out, int64_t* argmax_out, double* best_out);
+
 /* "built=<HIP_VERSION> runtime=<hipRuntimeGetVersion()> path=<shared object the HIP runtime was loaded from>".  Returns
  * GPX_ERR_UNSUPPORTED when the runtime the process resolved is not the major.minor this library was compiled against
  * (e.g. PyTorch's bundled libamdhip64 imported first), GPX_OK otherwise. */
@@ -212,6 +225,10 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  columns remain; 0 = never (28 / 40)
  *   "split_min_blocks" the split-panel schedule runs from this many block columns; below, one stream (3)
  *   "la_rows"      look-ahead column updates run on 64x64 tiles while at least this many rows remain below them; 0 = never (3072)
+ *   "batch_group"  batched draws (gpx_fit_predict_batch, gpx_sample_batch) with four or more draws: 2 | 4 = the bulk updates are
+ *                  grouped that many panels at a time from the first step to the last (a batch is throughput-bound throughout);
+ *                  the arithmetic is that of a single-draw call with "pair_min" = 1 and "quad_min" = 2 (4) or 0 (2).
+ *                  0 = the single-draw thresholds, i.e. the bits of default single-draw calls (4)
  *   "debug_force_timeout"  test hook: 1 = the first in-kernel wait of the next factorisation gives up at once, so the
  *                  GPX_ERR_RETRY path (kernel-boundary hand-overs, repeated call) can be exercised; clears itself (0) */
 int gpx_set_option(gpx_handle* h, const char* name, int64_t value);

@@ -343,21 +343,33 @@ def test_batched_draws_are_bit_identical_to_single_draws(core, n, d, m, kind, ar
     core.set_option("nb", 0)
     core.set_train(x)
     core.set_test(xn)
-    info, logp, mean, var = core.fit_predict_batch(plist, r, m_new, new_noise)
-    assert (info == 0).all()
-    info2, logp2, mean2, var2 = core.fit_predict_batch(plist, r, m_new, new_noise)
-    assert np.array_equal(logp, logp2) and np.array_equal(mean, mean2) and np.array_equal(var, var2)   # repeatable, bit for bit
-    for i in range(b):
-        i1, l1, m1, v1 = core.fit_predict(plist[i], r[i], m_new[i], float(new_noise[i]))
-        assert i1 == 0 and l1 == logp[i], (i, l1, logp[i])
-        assert np.array_equal(m1, mean[i]) and np.array_equal(v1, var[i]), i
-        if n <= 2000 or i < 2:
-            q = dict(draws[i])
-            if kind == 2:
-                q["k_period"] = per[i]
-            logp_ref, mean_ref, var_ref = orc.fit_predict(kind, x, y, xn, q, mean_value=means[i], observation_noise=bool(i % 2))
-            assert abs(l1 - logp_ref) <= 1e-10 * abs(logp_ref)
-            assert np.abs(m1 - mean_ref).max() <= 1e-8 * max(1.0, np.abs(mean_ref).max()) and np.abs(v1 - var_ref).max() <= 1e-8
+    # Two schedules: "batch_group" 0 = the single-draw grouping thresholds (the bits of DEFAULT single-draw calls); the
+    # default throughput mode for >= 4 draws groups the bulk updates four panels at a time throughout, which is what a
+    # single-draw call does with pair_min = 1, quad_min = 2.
+    for batch_group, single_opts in ((0, {}), (4, {"pair_min": 1, "quad_min": 2} if b >= 4 else {})):
+        core.set_option("batch_group", batch_group)
+        info, logp, mean, var = core.fit_predict_batch(plist, r, m_new, new_noise)
+        assert (info == 0).all()
+        info2, logp2, mean2, var2 = core.fit_predict_batch(plist, r, m_new, new_noise)
+        assert np.array_equal(logp, logp2) and np.array_equal(mean, mean2) and np.array_equal(var, var2)   # repeatable, bit for bit
+        try:
+            for name, v in single_opts.items():
+                core.set_option(name, v)
+            for i in range(b):
+                i1, l1, m1, v1 = core.fit_predict(plist[i], r[i], m_new[i], float(new_noise[i]))
+                assert i1 == 0 and l1 == logp[i], (batch_group, i, l1, logp[i])
+                assert np.array_equal(m1, mean[i]) and np.array_equal(v1, var[i]), (batch_group, i)
+                if n <= 2000 or i < 2:
+                    q = dict(draws[i])
+                    if kind == 2:
+                        q["k_period"] = per[i]
+                    logp_ref, mean_ref, var_ref = orc.fit_predict(kind, x, y, xn, q, mean_value=means[i], observation_noise=bool(i % 2))
+                    assert abs(l1 - logp_ref) <= 1e-10 * abs(logp_ref)
+                    assert np.abs(m1 - mean_ref).max() <= 1e-8 * max(1.0, np.abs(mean_ref).max()) and np.abs(v1 - var_ref).max() <= 1e-8
+        finally:
+            core.set_option("pair_min", 28)
+            core.set_option("quad_min", 40)
+            core.set_option("batch_group", 4)
 
 
 def test_batched_draws_report_info_per_draw(core):
@@ -417,3 +429,50 @@ def test_batched_device_resident_sampling_matches_oracle(core, conditioned, n, m
         ref = mean_ref[None, :] + eps[i] @ orc.cholesky_lower(cov_ref).T
         # chol(cov) amplifies differences in cov by ~1/sqrt(lambda_min(cov)) (>= 1/sqrt(noise + jitter))
         assert np.abs(smp[i] - ref).max() <= 1e-6, np.abs(smp[i] - ref).max()
+
+
+def test_device_acquisition_epilogue_matches_oracle_and_host_path():
+    """EI / UCB as a device epilogue over the resident (mu, sd) (``gpx_acquisition``) with the default Scale / Normalize
+    transforms: the values against the oracle's formulae on ``predict(fast=True)`` outputs, the arg-max, and the Halton
+    optimiser evaluating all its candidates in ONE posterior call against the same candidates pushed through in the
+    reference's batches of 100 (gpax/acquisition.py:166-216)."""
+    import gpax_amd
+    from gpax_amd import state
+    from gpax_amd.acquisition import ExpectedImprovement, UpperConfidenceBound
+    from oracle import gp_oracle as orc
+    from scipy.stats import qmc
+
+    rng = np.random.default_rng(4)
+    x = rng.uniform(0.0, 3.0, (300, 2))
+    y = 5.0 + 2.0 * np.sin(2 * x[:, 0]) * np.cos(x[:, 1]) + 0.05 * rng.standard_normal(300)
+    gp = gpax_amd.ExactGP(kernel=gpax_amd.MaternKernel(), x=x, y=y)          # default transforms
+    bounds = np.array([[0.0, 0.0], [3.0, 3.0]])
+    cand = rng.uniform(0.0, 3.0, (1234, 2))
+    for acq, ref in ((ExpectedImprovement(bounds), lambda mu, sd: orc.expected_improvement(mu, sd, y.max())),
+                     (UpperConfidenceBound(bounds, beta=4.0), lambda mu, sd: orc.upper_confidence_bound(mu, sd, 4.0)),
+                     (UpperConfidenceBound(bounds, beta=0.0), lambda mu, sd: mu),
+                     (UpperConfidenceBound(bounds, beta=float("inf")), lambda mu, sd: sd)):
+        state.set_rng_key(11)
+        vals = acq(gp, cand)
+        state.set_rng_key(11)
+        mu, sd = gp.predict(cand, fast=True)
+        want = ref(mu, sd)
+        assert vals.shape == (1234,) and np.abs(vals - want).max() <= 1e-11 * max(1.0, np.abs(want).max())
+        state.set_rng_key(11)
+        _, idx, best = gp._acquisition_fast(cand, acq.DEVICE_KIND, acq._device_param(gp), want_values=False)
+        # (this second call meets the cached factor and takes the solve path of gpx_posterior: same numbers to rounding)
+        assert idx == int(np.argmax(vals)) and abs(best - vals[idx]) <= 1e-11 * max(1.0, abs(vals[idx]))
+    # the optimiser: one call for all candidates == the reference's batched evaluation of the same candidates
+    ei = ExpectedImprovement(bounds)
+    state.set_rng_key(21)
+    x_star, val = ei.optimize(gp, 1500)
+    state.set_rng_key(21)
+    key, _ = state.get_rng_key()
+    samples = qmc.scale(qmc.Halton(d=2, seed=key).random(n=1500), bounds[0], bounds[1])
+    vals = ei(gp, samples)                       # same key sequence: one more get_rng_key inside
+    assert np.array_equal(x_star, samples[int(np.argmax(vals))][None, :]) and abs(val - vals.max()) <= 1e-11 * max(1.0, abs(val))
+    host = ExpectedImprovement(bounds, fast=True)
+    host.DEVICE_KIND = None                      # the host formula on predict() outputs, in batches of 100
+    state.set_rng_key(21)
+    x_host, val_host = host.optimize(gp, 1500)   # (re-draws the prior medians per batch, like the reference: compare loosely)
+    assert x_host.shape == x_star.shape and np.isfinite(val_host)

@@ -99,6 +99,41 @@ __global__ __launch_bounds__(256) void copy_kernel(v2d* dst, const v2d* src, siz
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// streaming read (16 B per lane, 4 loads in flight per thread per iteration), result kept live through a sum
+__global__ __launch_bounds__(256) void read_kernel(const v2d* src, size_t n, double* out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  double acc = 0.0;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const v2d a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    acc += a.x + a.y + b.x + b.y + c.x + c.y + d.x + d.y;
+  }
+  for (; i < n; i += stride) acc += src[i].x + src[i].y;
+  if (acc == 12345.678) out[0] = acc;
+}
+
+// write-only variants: 4 stores in flight per thread; non-temporal stores
+__global__ __launch_bounds__(256) void fill4_kernel(v2d* dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const v2d v = {1.0, 2.0};
+  for (; i + 3 * stride < n; i += 4 * stride) { dst[i] = v; dst[i + stride] = v; dst[i + 2 * stride] = v; dst[i + 3 * stride] = v; }
+  for (; i < n; i += stride) dst[i] = v;
+}
+__global__ __launch_bounds__(256) void fill_nt_kernel(v2d* dst, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const v2d v = {1.0, 2.0};
+  for (; i < n; i += stride) __builtin_nontemporal_store(v, &dst[i]);
+}
+// contiguous 1 KiB per wave-instruction, each workgroup owning one contiguous slab (the gram kernel's store shape: row segments)
+__global__ __launch_bounds__(256) void fill_slab_kernel(v2d* dst, size_t n) {
+  const size_t per = (n + gridDim.x - 1) / gridDim.x;
+  const size_t b0 = (size_t)blockIdx.x * per, b1 = b0 + per < n ? b0 + per : n;
+  const v2d v = {1.0, 2.0};
+  for (size_t i = b0 + threadIdx.x; i < b1; i += 256) dst[i] = v;
+}
+
 // in-kernel clock under an MFMA-dense loop: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime)
 __global__ __launch_bounds__(256) void clock_probe(double* out, unsigned long long* clk, int iters) {
   v4d acc[4];
@@ -182,6 +217,24 @@ int main() {
     float msf = time_ms([&] { hipLaunchKernelGGL(fill_kernel, grid, block, 0, 0, a, n); }, 5);
     float msc = time_ms([&] { hipLaunchKernelGGL(copy_kernel, grid, block, 0, 0, b, a, n); }, 5);
     printf("HBM fill (write only): %.2f TB/s ; copy (read+write): %.2f TB/s\n", bytes / msf * 1e-9, 2.0 * bytes / msc * 1e-9);
+    // The guide's 6.0-6.3 TB/s figures (MI355X_MICROARCH.md:296,332,351) are a streaming READ of a 1.2 GB table and plain
+    // stores into 75 / 302 MB tables (the smaller one inside the 256 MB Infinity Cache).  Reads, the store variants and a
+    // cache-sized footprint, to see which ceiling a 2 GiB write stream -- the gram build's traffic -- actually has here:
+    for (int wpc : {8, 16, 32}) {
+      dim3 g2(cus * wpc / 4);
+      float msr = time_ms([&] { hipLaunchKernelGGL(read_kernel, g2, block, 0, 0, a, n, out); }, 5);
+      float ms4 = time_ms([&] { hipLaunchKernelGGL(fill4_kernel, g2, block, 0, 0, a, n); }, 5);
+      float msn = time_ms([&] { hipLaunchKernelGGL(fill_nt_kernel, g2, block, 0, 0, a, n); }, 5);
+      float mss = time_ms([&] { hipLaunchKernelGGL(fill_slab_kernel, g2, block, 0, 0, a, n); }, 5);
+      printf("2 GiB, %2d waves/CU: read %.2f TB/s ; fill x4 in flight %.2f ; fill non-temporal %.2f ; fill slab-per-workgroup %.2f TB/s\n", wpc,
+             bytes / msr * 1e-9, bytes / ms4 * 1e-9, bytes / msn * 1e-9, bytes / mss * 1e-9);
+    }
+    for (size_t mb : {64, 128, 512}) {
+      const size_t nb = (mb << 20) / sizeof(v2d);
+      float msr = time_ms([&] { hipLaunchKernelGGL(read_kernel, grid, block, 0, 0, a, nb, out); }, 20);
+      float msw = time_ms([&] { hipLaunchKernelGGL(fill_kernel, grid, block, 0, 0, a, nb); }, 20);
+      printf("%4zu MiB footprint (Infinity Cache is 256 MiB), repeated: read %.2f TB/s ; fill %.2f TB/s\n", mb, (mb << 20) / msr * 1e-9, (mb << 20) / msw * 1e-9);
+    }
     CHECK(hipFree(a)); CHECK(hipFree(b));
   }
   return 0;
