@@ -101,6 +101,9 @@ SIGNATURES = {
     "gpx_dist_step_update": (C.c_int, [C.c_void_p, C.c_int64]),
     "gpx_dist_step_gather": (C.c_int, [C.c_void_p, C.c_int64]),
     "gpx_dist_step_update_cols": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int]),
+    "gpx_dist_step_gather_group": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int]),
+    "gpx_dist_step_update_group": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "gpx_dist_group_size": (C.c_int, [C.c_void_p, C.c_int64]),
     "gpx_dist_buffers": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p),
                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "gpx_dist_copy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),

@@ -47,6 +47,29 @@ static int dist_ensure(gpx_handle* h, T** p, int64_t* cap, int64_t count) {
   return GPX_OK;
 }
 
+// Optionally (GPX_DIST_RESERVED_CUS=n, default 0 = off) the bulk passes of the distributed driver run on a stream whose CU
+// mask leaves n CUs (n / 8 per XCD) to the chain.  potrf_diag is ONE workgroup that needs a whole CU (144 KB of LDS, 2 x 208
+// VGPRs per SIMD); behind a saturating bulk pass -- three 168-VGPR workgroups per CU, refilled one by one as they finish --
+// no CU ever frees up, and the kernel waits the pass out: measured 174 us per potrf_diag on average (2.3 ms at worst) at
+// N = 16384 on one rank, 22 of the step's 40 ms.  The single-GPU schedule avoids that wait by starting potrf_diag resident
+// a step early.  Measured here (one rank, N = 16384): 39.8 ms without a mask, 41.0 / 40.8 / 38.1 ms with 8 / 16 / 32 CUs
+// reserved -- the mask does not buy the chain a CU reliably; the fix on the list is the resident early diagonal.
+static hipStream_t bulk_stream(gpx_handle* h) {
+  DistState& D = h->dist;
+  if (D.s_bulk) return D.s_bulk;
+  const char* env = getenv("GPX_DIST_RESERVED_CUS");
+  int drop = env ? atoi(env) : 0;
+  const int ncu = h->prop.multiProcessorCount;
+  if (drop <= 0 || drop >= ncu) return h->s_trail;
+  drop = (drop + 7) / 8 * 8;   // mask bit i is CU i / 8 of XCD i % 8: the first `drop` bits take drop / 8 CUs from every XCD
+  std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+  for (int i = drop; i < ncu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)mask.size(), mask.data()) != hipSuccess) return h->s_trail;
+  D.s_bulk = st;
+  return st;
+}
+
 // ---------------------------------------------------------------------------------- layout
 // global row blocks: [0, nblk) the matrix, [nblk, nblk + eblk) the border (k_cross rows, then r)
 static inline int64_t owner_of(const DistState& d, int64_t i) { return i % d.P; }
@@ -79,6 +102,18 @@ __global__ void dist_unpermute_kernel(double* panel, const double* recv, int64_t
   const double* src = recv + ((int64_t)r * chunk_rows + (i / P - s0) * nb) * nb;
   double* dst = panel + (int64_t)blockIdx.x * nb * nb;
   for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) dst[e] = src[e];
+}
+
+// the same chunks into a group buffer: block row i (absolute) -> rows [i nb, (i+1) nb), columns [slot nb, (slot+1) nb) of G (ld = ldg)
+__global__ void dist_unpermute_group_kernel(double* G, int64_t ldg, int slot, const double* recv, int64_t k, int64_t RB, int P, int nb,
+                                            int64_t chunk_rows) {
+  const int64_t i = k + 1 + blockIdx.x;   // global block
+  if (i >= RB) return;
+  const int r = (int)(i % P);
+  const int64_t s0 = k >= r ? (k - r) / P + 1 : 0;
+  const double* src = recv + ((int64_t)r * chunk_rows + (i / P - s0) * nb) * nb;
+  double* dst = G + i * nb * ldg + (int64_t)slot * nb;
+  for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) dst[(int64_t)(e / nb) * ldg + e % nb] = src[e];
 }
 
 __global__ __launch_bounds__(256) void dist_logdet_kernel(const double* L, int64_t ld, int64_t nslots, int P, int rank,
@@ -125,6 +160,10 @@ extern "C" int gpx_dist_configure(gpx_handle* h, int rank, int nranks, const dou
   GPX_RET(dist_ensure(h, &D.recv, &D.recv_cap, (int64_t)nranks * D.chunk_rows * nb));
   GPX_RET(dist_ensure(h, &D.panel, &D.panel_cap, D.RB * nb * nb));
   GPX_RET(dist_ensure(h, &D.panel2, &D.panel2_cap, D.RB * nb * nb));
+  // grouped bulk updates: two K-contiguous group buffers, (RB nb) rows x (GPX_DIST_GMAX nb) columns each -- the gathered
+  // panels of a group side by side, indexed by ABSOLUTE block row, so that one K = g nb pass can apply them all
+  GPX_RET(dist_ensure(h, &D.group[0], &D.group_cap[0], D.RB * nb * (int64_t)GPX_DIST_GMAX * nb));
+  GPX_RET(dist_ensure(h, &D.group[1], &D.group_cap[1], D.RB * nb * (int64_t)GPX_DIST_GMAX * nb));
   GPX_RET(dist_ensure(h, &D.xloc, &D.xloc_cap, rows * d));
   GPX_RET(dist_ensure(h, &D.gid, &D.gid_cap, rows));
   GPX_RET(dist_ensure(h, &D.type, &D.type_cap, rows));
@@ -283,7 +322,7 @@ static int dist_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t nc
   t.M = mrows; t.N = ncol * nb; t.K = nb; t.alpha = -1.0; t.beta = 1.0;
   t.lower = 1; t.row_off = s0 * nb; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 0;
   t.cyc_P = D.P; t.cyc_r = D.rank; t.cyc_nb = nb;
-  return launch_gemm_nt(h, on_trail ? h->s_trail : h->s_main, t);
+  return launch_gemm_nt(h, on_trail ? bulk_stream(h) : h->s_main, t);
 }
 
 extern "C" int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t ncol, int on_trail) {
@@ -315,6 +354,48 @@ extern "C" int gpx_dist_step_diag_early(gpx_handle* h, int64_t k1) {
   p.nb = nb; p.A = D.A + sl * nb * D.ld + c1; p.lda = D.ld; p.L = D.L + sl * nb * D.ld + c1; p.ldl = D.ld; p.W = D.W;
   p.info = h->d_info; p.col0 = (int)c1;
   return launch_potrf_diag(h, h->s_main2, p);
+}
+
+// Grouped schedule: the received chunks of panel k into group buffer `buf` (0 | 1), column slot `slot` (= k - first panel of the group)
+extern "C" int gpx_dist_step_gather_group(gpx_handle* h, int64_t k, int slot, int buf) {
+  DistState& D = h->dist;
+  if (slot < 0 || slot >= GPX_DIST_GMAX || (buf != 0 && buf != 1)) { gpx_set_error(h, "gpx_dist_step_gather_group: bad slot / buffer"); return GPX_ERR_ARG; }
+  const int64_t nbelow = D.RB - k - 1;
+  if (nbelow <= 0) return GPX_OK;
+  hipLaunchKernelGGL(dist_unpermute_group_kernel, dim3((unsigned)nbelow), dim3(256), 0, h->s_main, D.group[buf], (int64_t)GPX_DIST_GMAX * h->nb,
+                     slot, D.recv, k, D.RB, D.P, h->nb, D.gather_stride_rows > 0 ? D.gather_stride_rows : D.chunk_rows);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
+// Grouped schedule: own block rows after global block k = kfirst + npan - 1, matrix block columns [cfirst, cfirst + ncol)
+// (ncol < 0: to the right edge) -= panels kfirst .. k in ONE K = npan nb pass against group buffer `buf`
+extern "C" int gpx_dist_step_update_group(gpx_handle* h, int64_t kfirst, int64_t npan, int64_t cfirst, int64_t ncol, int on_trail, int buf) {
+  DistState& D = h->dist;
+  const int nb = h->nb;
+  if (npan < 1 || npan > GPX_DIST_GMAX || (buf != 0 && buf != 1)) { gpx_set_error(h, "gpx_dist_step_update_group: bad group"); return GPX_ERR_ARG; }
+  const int64_t k = kfirst + npan - 1;
+  if (cfirst < k + 1) cfirst = k + 1;
+  if (ncol < 0 || cfirst + ncol > D.nblk) ncol = D.nblk - cfirst;
+  // own rows from global block cfirst on: the blocks between k+1 and cfirst have no lower tile in these columns (and on one
+  // rank the launch is then the square-topped trapezoid that the 1-D tile enumeration serves without empty workgroups)
+  const int64_t s0 = first_slot_after(D, D.rank, cfirst - 1);
+  const int64_t mrows = (D.nloc - s0) * nb, ldg = (int64_t)GPX_DIST_GMAX * nb;
+  if (mrows <= 0 || ncol <= 0) return GPX_OK;
+  GemmLaunch t;
+  t.A = D.L + s0 * nb * D.ld + kfirst * nb; t.lda = D.ld;          // own rows: the group's panels are adjacent columns of L
+  t.B = D.group[buf] + cfirst * nb * ldg; t.ldb = ldg;              // rows of global blocks cfirst .. (B rows = matrix columns)
+  t.C = D.A + s0 * nb * D.ld + cfirst * nb; t.ldc = D.ld;
+  t.M = mrows; t.N = ncol * nb; t.K = npan * nb; t.alpha = -1.0; t.beta = 1.0;
+  t.lower = 1; t.row_off = s0 * nb; t.col_off = cfirst * nb; t.b_lower_tri = 0; t.small_tile = 0;
+  t.cyc_P = D.P; t.cyc_r = D.rank; t.cyc_nb = nb;
+  return launch_gemm_nt(h, on_trail ? bulk_stream(h) : h->s_main, t);
+}
+
+// group size by the block columns still to go: the single-GPU thresholds ("quad_min" / "pair_min")
+extern "C" int gpx_dist_group_size(gpx_handle* h, int64_t left) {
+  if (!h) return 1;
+  return (h->quad_min > 0 && left > h->quad_min) ? 4 : ((h->pair_min > 0 && left > h->pair_min) ? 2 : 1);
 }
 
 extern "C" int gpx_dist_step_update(gpx_handle* h, int64_t k) {
@@ -452,7 +533,7 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
   // step later, so the only wait on the critical path is for the PREVIOUS step's bulk update.
   const char* la_env = getenv("GPX_DIST_LOOKAHEAD");   // read per call (tests switch it)
   const int dist_la = la_env ? atoi(la_env) : 1;
-  hipStream_t t = h->s_trail;
+  hipStream_t t = bulk_stream(h);
   while ((int64_t)D.ev_s.size() < D.nblk) {
     hipEvent_t a, b;
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&a, hipEventDisableTiming | hipEventDisableSystemFence));
@@ -472,6 +553,17 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
     GPX_HIP_CHECK(h, hipEventCreateWithFlags(&b, hipEventDisableTiming | hipEventDisableSystemFence));
     D.ev_pan.push_back(a); D.ev_diag.push_back(b);
   }
+  // Grouped bulk updates (with the look-ahead, not with the early diagonal): as in the single-GPU schedule the bulk stream
+  // applies the g most recent panels in ONE K = g nb pass every g-th step (g = 4 / 2 / 1 by the block columns still to go),
+  // which cuts the read-modify-write passes over the trailing rows g-fold; the gathered panels of a group sit side by
+  // side in a K-contiguous group buffer, and the main stream brings block column k+1 up to date with the panels since
+  // the last bulk pass at every step.  Two group buffers alternate: the bulk pass of one group reads its buffer while
+  // the next group's panels arrive.
+  const char* gr_env = getenv("GPX_DIST_GROUP");
+  const bool grouped = dist_la && !early && !(gr_env && atoi(gr_env) == 0);
+  const char* p2p_env = getenv("GPX_DIST_P2P");
+  const bool p2p = p2p_env && atoi(p2p_env) != 0;
+  int64_t last_t = -1, group_end = -1, prev_t = -1; int gbuf = 0;
   for (int64_t k = 0; k < D.nblk; ++k) {
     if (!early || k == 0) GPX_RET(gpx_dist_step_diag(h, k));
     else if (owner_of(D, k) == D.rank) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_diag[(size_t)k], 0));   // potrf_diag(k) ran early on `e`
@@ -490,10 +582,53 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
     for (int r = 0; r < D.P; ++r) step_rows = std::max(step_rows, (nloc_of(D, r) - first_slot_after(D, r, k)) * nb);
     D.gather_stride_rows = step_rows;
     if (step_rows > 0) {
-      if (comm) GPX_NCCL_CHECK(h, ncclAllGather(D.send, D.recv, (size_t)(step_rows * nb), ncclDouble, comm, s));
-      else GPX_HIP_CHECK(h, hipMemcpyAsync(D.recv, D.send, (size_t)(step_rows * nb) * sizeof(double), hipMemcpyDeviceToDevice, s));
+      const size_t cnt = (size_t)(step_rows * nb);
+      if (comm && p2p && D.P > 1) {
+        // xGMI is point-to-point (7 links per GPU): instead of a ring all-gather, which is bound by ONE link, every rank
+        // sends its chunk to every peer directly -- 7 concurrent transfers, one per link (GPX_DIST_P2P=1)
+        GPX_NCCL_CHECK(h, ncclGroupStart());
+        for (int peer = 0; peer < D.P; ++peer) {
+          if (peer == D.rank) continue;
+          GPX_NCCL_CHECK(h, ncclSend(D.send, cnt, ncclDouble, peer, comm, s));
+          GPX_NCCL_CHECK(h, ncclRecv(D.recv + (size_t)peer * cnt, cnt, ncclDouble, peer, comm, s));
+        }
+        GPX_NCCL_CHECK(h, ncclGroupEnd());
+        GPX_HIP_CHECK(h, hipMemcpyAsync(D.recv + (size_t)D.rank * cnt, D.send, cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+      } else if (comm) {
+        GPX_NCCL_CHECK(h, ncclAllGather(D.send, D.recv, cnt, ncclDouble, comm, s));
+      } else {
+        GPX_HIP_CHECK(h, hipMemcpyAsync(D.recv, D.send, cnt * sizeof(double), hipMemcpyDeviceToDevice, s));
+      }
     }
     if (!dist_la) { GPX_RET(gpx_dist_step_update(h, k)); D.gather_stride_rows = 0; continue; }
+    if (grouped) {
+      if (k > group_end) group_end = std::min<int64_t>(D.nblk - 1, k + gpx_dist_group_size(h, D.nblk - k) - 1);
+      const int64_t kfirst = last_t + 1, npan = k - last_t;
+      GPX_RET(gpx_dist_step_gather_group(h, k, (int)(k - kfirst), gbuf));
+      D.gather_stride_rows = 0;
+      // column k+1 gets every panel it still lacks; it lies in the near block of the previous group end (below), so the
+      // chain never waits for a bulk pass inside a group
+      GPX_RET(gpx_dist_step_update_group(h, kfirst, npan, k + 1, 1, 0, gbuf));
+      if (k == group_end) {
+        // Near block: the NEXT group's columns (k+2 .. k+1+g_next) get this group's panels from the main stream, in one
+        // K = npan nb launch; the bulk pass starts behind them.  With the bulk pass covering everything from column k+2
+        // the chain would stall at the first step of every group until that pass had finished, and the bulk stream would
+        // then idle for the g chain steps that produce its next panels (~25 % of the time at g = 4).
+        const int64_t g_next = k + 1 < D.nblk ? gpx_dist_group_size(h, D.nblk - (k + 1)) : 0;
+        const int64_t near = std::max<int64_t>(0, std::min<int64_t>(g_next, D.nblk - (k + 2)));
+        if (near > 0) {
+          if (prev_t >= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)prev_t], 0));   // those columns were last written by the previous bulk pass
+          GPX_RET(gpx_dist_step_update_group(h, kfirst, npan, k + 2, near, 0, gbuf));
+        }
+        GPX_HIP_CHECK(h, hipEventRecord(D.ev_s[(size_t)k], s));
+        GPX_HIP_CHECK(h, hipStreamWaitEvent(t, D.ev_s[(size_t)k], 0));
+        GPX_RET(gpx_dist_step_update_group(h, kfirst, npan, k + 2 + near, -1, 1, gbuf));                    // the bulk pass, K = npan nb
+        GPX_HIP_CHECK(h, hipEventRecord(D.ev_t[(size_t)k], t));
+        prev_t = k;
+        last_t = k; gbuf ^= 1;
+      }
+      continue;
+    }
     GPX_RET(gpx_dist_step_gather(h, k));
     D.gather_stride_rows = 0;
     if (k >= 1) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)(k - 1)], 0));   // column k+1 was last written by the bulk update of step k-1
@@ -503,8 +638,9 @@ extern "C" int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, c
     GPX_HIP_CHECK(h, hipStreamWaitEvent(t, D.ev_s[(size_t)k], 0));
     GPX_RET(gpx_dist_step_update_cols(h, k, k + 2, -1, 1));
     GPX_HIP_CHECK(h, hipEventRecord(D.ev_t[(size_t)k], t));
+    last_t = k;
   }
-  if (dist_la && D.nblk > 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)(D.nblk - 1)], 0));
+  if (dist_la && last_t >= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(s, D.ev_t[(size_t)last_t], 0));
   GPX_RET(gpx_dist_extract_z(h));
   if (comm) GPX_NCCL_CHECK(h, ncclBroadcast(D.z, D.z, (size_t)D.npad, ncclDouble, D.r_owner, comm, s));
   const int64_t nt = (int64_t)D.test_rows.size();
@@ -544,8 +680,9 @@ void gpx_dist_free(gpx_handle* h) {
   for (auto e : D.ev_pan) (void)hipEventDestroy(e);
   for (auto e : D.ev_diag) (void)hipEventDestroy(e);
   D.ev_s.clear(); D.ev_t.clear(); D.ev_pan.clear(); D.ev_diag.clear();
-  void* bufs[] = {D.A, D.L, D.W, D.send, D.recv, D.panel, D.panel2, D.xloc, D.gid, D.type, D.r, D.z, D.small, D.red};
+  void* bufs[] = {D.A, D.L, D.W, D.send, D.recv, D.panel, D.panel2, D.xloc, D.gid, D.type, D.r, D.z, D.small, D.red, D.group[0], D.group[1]};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (D.comm) (void)ncclCommDestroy((ncclComm_t)D.comm);
+  if (D.s_bulk) (void)hipStreamDestroy(D.s_bulk);
   D = DistState();
 }

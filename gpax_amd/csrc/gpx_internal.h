@@ -179,12 +179,14 @@ int launch_utri_gemv(gpx_handle* h, hipStream_t s, const double* U, int64_t ld, 
                      int64_t n, int64_t ncols);
 
 // ---------------------------------------------------------------- distributed state (dist.hip)
+#define GPX_DIST_GMAX 4   // panels per grouped bulk pass, at most
 struct DistState {
   bool configured = false, have_r = false;
   int rank = 0, P = 1, d = 0;
   int64_t n = 0, m = 0, npad = 0, nblk = 0, eblk = 0, RB = 0, nloc = 0, ld = 0, chunk_rows = 0;
   int kind = 0; double k_scale = 0, k_jitter = 0;
   double *A = nullptr, *L = nullptr, *W = nullptr, *send = nullptr, *recv = nullptr, *panel = nullptr;
+  double* group[2] = {nullptr, nullptr}; int64_t group_cap[2] = {0, 0};   // K-contiguous group buffers of the grouped bulk updates
   double* panel2 = nullptr; int64_t panel2_cap = 0;   // panels alternate between two buffers: the bulk update of step k still
                                                         // reads panel k while step k+1 gathers the next one (look-ahead)
   std::vector<hipEvent_t> ev_s, ev_t;                   // look-ahead hand-overs of the RCCL driver
@@ -196,6 +198,7 @@ struct DistState {
   int r_owner = 0; int64_t r_local_row = -1;
   std::vector<std::pair<int64_t, int64_t>> test_rows;   // (local row, test index) of the k_cross rows held here
   void* comm = nullptr;                                  // ncclComm_t
+  hipStream_t s_bulk = nullptr;                          // bulk stream on a CU mask that leaves a few CUs to the chain (dist.hip)
   int64_t gather_stride_rows = 0;                        // rows per rank in `recv` for the step being gathered (0: chunk_rows)
 };
 void gpx_dist_free(gpx_handle* h);

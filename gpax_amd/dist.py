@@ -61,10 +61,13 @@ class _Rank:
 class LoopbackGroup:
     """P virtual ranks on ONE GPU; collectives are device-to-device copies.  Test transport only."""
 
-    def __init__(self, nranks, x, x_new, y_minus_m, device=0, nb=128, early_diag=False):
+    def __init__(self, nranks, x, x_new, y_minus_m, device=0, nb=128, early_diag=False, grouped=False):
         """``early_diag``: play the early-diagonal schedule of ``gpx_dist_fit_predict`` (the owner of block k+1 updates
-        and factorises its diagonal block from its own panel rows, before the all-gather of panel k)."""
+        and factorises its diagonal block from its own panel rows, before the all-gather of panel k).
+        ``grouped``: play its grouped schedule (the default of the RCCL driver): the gathered panels of a group go side
+        by side into a K-contiguous group buffer and the bulk pass applies them in one K = g nb launch."""
         self.early_diag = early_diag
+        self.grouped = grouped and not early_diag
         self.P = nranks
         self.ranks = []
         for r in range(nranks):
@@ -83,6 +86,7 @@ class LoopbackGroup:
         for r in R:
             r.core._check(r.lib.gpx_dist_build(r.h, C.byref(p), float(new_noise)), "gpx_dist_build")
         bufs = [r.buffers() for r in R]
+        last_t, group_end, gbuf = -1, -1, 0
         for k in range(R[0].nsteps):
             owner = k % self.P
             if not (self.early_diag and k >= 1):   # early schedule: block k was factorised during step k-1
@@ -102,6 +106,24 @@ class LoopbackGroup:
                 for r in range(self.P):
                     dst = bufs[q]["recv"] + r * bufs[q]["chunk"] * 8
                     R[q].core._check(R[q].lib.gpx_dist_copy(R[q].h, dst, bufs[r]["send"], bufs[q]["chunk"]), "allgather")
+            if self.grouped:   # the grouped driver: column k+1 gets every panel since the last bulk pass; the bulk pass at group ends
+                nblk = R[0].nsteps
+                if k > group_end:
+                    group_end = min(nblk - 1, k + R[0].lib.gpx_dist_group_size(R[0].h, nblk - k) - 1)
+                kfirst, npan = last_t + 1, k - last_t
+                for r in R:
+                    r.core._check(r.lib.gpx_dist_step_gather_group(r.h, k, k - kfirst, gbuf), "step_gather_group")
+                    r.core._check(r.lib.gpx_dist_step_update_group(r.h, kfirst, npan, k + 1, 1, 0, gbuf), "step_update_group (next)")
+                    if k == group_end:   # near block (the next group's columns) and the bulk pass behind it, as the RCCL driver splits them
+                        g_next = r.lib.gpx_dist_group_size(r.h, nblk - (k + 1)) if k + 1 < nblk else 0
+                        near = max(0, min(g_next, nblk - (k + 2)))
+                        if near > 0:
+                            r.core._check(r.lib.gpx_dist_step_update_group(r.h, kfirst, npan, k + 2, near, 0, gbuf), "step_update_group (near)")
+                        r.core._check(r.lib.gpx_dist_step_update_group(r.h, kfirst, npan, k + 2 + near, -1, 0, gbuf), "step_update_group (bulk)")
+                    r.core.synchronize()
+                if k == group_end:
+                    last_t, gbuf = k, gbuf ^ 1
+                continue
             for r in R:  # the look-ahead driver's split of the update: block column k+1 first, then the rest
                 r.core._check(r.lib.gpx_dist_step_gather(r.h, k), "step_gather")
                 if self.early_diag:

@@ -30,7 +30,9 @@ int gpx_dist_comm_destroy(gpx_handle* h);
 
 /* Whole distributed fit+predict step (gram of own block rows, factorisation with RCCL broadcast /
  * all-gather per panel, log-marginal, posterior mean / variance); outputs complete on every rank.
- * The all-gather of step k moves max_r(rows rank r still holds below block k) x nb doubles per rank. */
+ * The all-gather of step k moves max_r(rows rank r still holds below block k) x nb doubles per rank; GPX_DIST_P2P=1 replaces
+ * it by direct per-peer ncclSend / ncclRecv pairs in one group (xGMI is point-to-point: 7 concurrent transfers, one per link,
+ * instead of a ring bound by a single link). */
 int gpx_dist_fit_predict(gpx_handle* h, const gpx_kernel_params* p, const double* m_new, double new_noise,
                          double* logp, double* mean_out, double* var_out);
 
@@ -50,6 +52,13 @@ int gpx_dist_step_update_cols(gpx_handle* h, int64_t k, int64_t cfirst, int64_t 
  * update of block column k+1 that leaves that block row out on its owner */
 int gpx_dist_step_diag_early(gpx_handle* h, int64_t k1);
 int gpx_dist_step_update_next_col(gpx_handle* h, int64_t k);
+/* grouped bulk updates (the default of gpx_dist_fit_predict with the look-ahead; GPX_DIST_GROUP=0 switches them off): the
+ * received chunks of panel k into column slot `slot` of the K-contiguous group buffer `buf` (0 | 1), and the update of the
+ * matrix block columns [cfirst, cfirst+ncol) by the npan panels from kfirst on in ONE K = npan nb pass; the group size by
+ * the block columns still to go (options "pair_min" / "quad_min", as on one GPU) */
+int gpx_dist_step_gather_group(gpx_handle* h, int64_t k, int slot, int buf);
+int gpx_dist_step_update_group(gpx_handle* h, int64_t kfirst, int64_t npan, int64_t cfirst, int64_t ncol, int on_trail, int buf);
+int gpx_dist_group_size(gpx_handle* h, int64_t left);
 int gpx_dist_buffers(gpx_handle* h, void** w, int64_t* w_count, void** send, void** recv, int64_t* chunk_count,
                      void** z, int64_t* z_count);
 int gpx_dist_copy(gpx_handle* h, void* dst, const void* src, int64_t count);   /* device-to-device, doubles */
