@@ -224,12 +224,13 @@ struct SplitSchedule {
     h = hh; c = make_ctx(h, M, tri_base);
     nb = c.nb; nblk = c.nblk; B = (double)M.batch;
     P = h->s_main; Q = h->s_far; T = h->s_trail;
-    // Batched draws hand over at kernel boundaries: a resident consumer holds its CU slots (and LDS) while it sleeps, and its
-    // grid grows with the batch -- 16 band workgroups per draw park 34 KB of LDS each on as many CUs, and from 16 draws on
-    // no CU is left with the 144 KB potrf_diag needs (measured: the wait times out, info = -7); the last panel's waiting
-    // grid (border tiles x draws) can likewise fill every slot its own producer needs.  With several draws in flight the
-    // GPU is throughput-bound anyway; the bits do not depend on the hand-over mode.
-    resident = h->resident != 0 && h->prof_mode != 1 && nblk >= 3 && M.batch == 1;
+    // Batches of more than four draws hand over at kernel boundaries: a resident consumer holds its CU slots (and LDS)
+    // while it sleeps, and its grid grows with the batch -- 16 band workgroups per draw park 34 KB of LDS each on as many
+    // CUs, and from 16 draws on no CU is left with the 144 KB potrf_diag needs (measured: the wait times out, info = -7).
+    // Up to four draws the chain still matters (N = 4096, two draws: 1.57 ms per draw with kernel boundaries, 1.33 resident)
+    // and 64 sleeping band workgroups + 4 potrf_diag leave the GPU to their producers; the last panel's in-kernel wait
+    // (border tiles x draws waiting workgroups) stays a single-draw device.  The bits do not depend on the hand-over mode.
+    resident = h->resident != 0 && h->prof_mode != 1 && nblk >= 3 && M.batch <= 4;
     P2 = resident ? h->s_main2 : P;
     chain2 = resident && h->resident >= 2;
     fuse_band = chain2;
@@ -294,7 +295,7 @@ struct SplitSchedule {
         if (gn >= 2) near = std::max<int64_t>(0, std::min<int64_t>(gn, nblk - (j + 3)));
       }
       const int64_t mr = rows - (j + 2) * nb, ncb = std::min<int64_t>(2, nblk - (j + 1));
-      if (chain2 && j == nblk - 2 && j - lt == 1 && mr > 0 && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) lp_flag = true;
+      if (chain2 && c.M.batch == 1 && j == nblk - 2 && j - lt == 1 && mr > 0 && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) lp_flag = true;
       if (use_dib && mr > 0 && ncb > 1 && j - lt == 1) {
         dib[(size_t)(j + 1)] = 1;
         band_t[(size_t)(j + 1)] = (ti >= 0 && j + 2 >= tf) ? ti : -1;

@@ -50,6 +50,22 @@ __global__ void probe(double* io, unsigned long long* clk) {
         a[i] = fma(__hiloint2double(hi, lo), m, a[i]);
         asm volatile("" : "+v"(a[i]), "+v"(s));
       }
+    } else if (MODE == 9) {  // 16 independent v_fma_f64 with only 16 lanes active (EXEC = 0xffff): are empty passes skipped?
+      asm volatile("s_mov_b64 exec, 0xffff" ::: "exec");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(a[i]) : "v"(s), "v"(m));
+      asm volatile("s_mov_b64 exec, -1" ::: "exec");
+    } else if (MODE == 10) {  // 16 independent v_fmac_f64_dpp with EXEC = 0xffff
+      asm volatile("s_mov_b64 exec, 0xffff" ::: "exec");
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:3 row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(s), "v"(m));
+      asm volatile("s_mov_b64 exec, -1" ::: "exec");
+    } else if (MODE == 11) {  // dependent chain of 16 v_fma_f64 with EXEC = 0xffff (latency)
+      asm volatile("s_mov_b64 exec, 0xffff" ::: "exec");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a[0]) : "v"(m), "v"(s));
+      asm volatile("s_mov_b64 exec, -1" ::: "exec");
     } else if (MODE == 8) {  // dependent chain of 16 v_fmac_f64_dpp on one accumulator
 #pragma unroll
       for (int i = 0; i < 16; ++i)
@@ -65,13 +81,14 @@ int main() {
   double* io; unsigned long long* clk; (void)hipMalloc(&io, 64 * 17 * 8); (void)hipMalloc(&clk, 16 * 8);
   (void)hipMemset(io, 0, 64 * 17 * 8);
 #define RUN(M) hipLaunchKernelGGL(probe<M>, dim3(1), dim3(64), 0, 0, io, clk); hipLaunchKernelGGL(probe<M>, dim3(1), dim3(64), 0, 0, io, clk);
-  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8)
+  RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11)
   (void)hipDeviceSynchronize();
   unsigned long long h[16]; (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
   const char* names[] = {"v_fma_f64 indep (per instr)", "s_nop1+v_fmac_f64_dpp indep", "v_fmac_f64_dpp indep", "v_mov_b64_dpp+v_fma_f64 pair",
                          "v_fma_f64 dependent (latency)", "v_rsq_f64+v_mul_f64 dependent pair", "nop+v_mov_b64_dpp+v_fma_f64 dependent pair",
-                         "2x v_mov_b32_dpp + v_fma_f64", "v_fmac_f64_dpp dependent"};
-  const int per[] = {16, 16, 16, 16, 16, 8, 8, 16, 16};
-  for (int m = 0; m < 9; ++m) printf("%-45s %.1f cycles\n", names[m], (double)h[m] / 64.0 / per[m]);
+                         "2x v_mov_b32_dpp + v_fma_f64", "v_fmac_f64_dpp dependent", "v_fma_f64 indep, EXEC=0xffff",
+                         "v_fmac_f64_dpp indep, EXEC=0xffff", "v_fma_f64 dependent, EXEC=0xffff"};
+  const int per[] = {16, 16, 16, 16, 16, 8, 8, 16, 16, 16, 16, 16};
+  for (int m = 0; m < 12; ++m) printf("%-45s %.1f cycles\n", names[m], (double)h[m] / 64.0 / per[m]);
   return 0;
 }

@@ -1,13 +1,14 @@
 #!/bin/bash
-# Regenerates the judged evidence under gpurun_out/refresh/ on the GPU box (copy what is kept into profiles/):
-#   bench line, rocprofv3 kernel stats of the same command, PMC traffic passes (separate runs), size sweep, step timeline.
+# Regenerates the judged evidence under gpurun_out/refresh/ on the GPU box (copy what is kept into profiles/ as rNN_*):
+#   bench line, rocprofv3 kernel stats of the same command, PMC traffic passes (separate runs), size sweep, step timeline,
+#   batched-draw kernel stats, one-rank distributed kernel stats, peak microbenchmarks, small-N latencies.
 # Usage (from the repo root on the box): bash tools/refresh_profiles.sh
-set -e -o pipefail
+set -o pipefail
 R=$PWD
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-echo "bench done"; tail -c 300 $OUT/bench.json; echo
+echo "bench done"; tail -c 200 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o k -- python3 $R/bench.py --no-cpu-baseline --no-sweep > $OUT/stats_bench.json 2> $OUT/stats.err
 echo "kernel stats done"
@@ -15,12 +16,22 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- python3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- python3 $R/bench.py --no-cpu-baseline --no-sweep --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_write.err
 rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/pmc_mfma -o p -- python3 $R/bench.py --no-cpu-baseline --no-sweep --steps 5 --warmup 2 > /dev/null 2> $OUT/pmc_mfma.err
 echo "pmc done"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_b -o k -- python3 $R/tools/batch_sweep.py 4096 16 28:40 > $OUT/batched16.txt 2> $OUT/stats_b.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_d -o k -- python3 $R/bench.py --workload dist --dist-rehearsal --n 16384 --steps 3 --warmup 2 > $OUT/dist_rehearsal.json 2> $OUT/stats_d.err
 cd $R
 python3 tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/traffic.json $OUT/pmc_mfma > /dev/null
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
-rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/stats
+find $OUT/stats_b -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_batched16.csv \;
+find $OUT/stats_d -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_dist_one_rank.csv \;
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/stats $OUT/stats_b $OUT/stats_d
 python3 tools/sweep.py --out $OUT/sweep.json > $OUT/sweep.md 2> $OUT/sweep.err
 echo "sweep done"
-python3 tools/timeline2.py 4096 12 15 > $OUT/step_timeline.txt 2>&1 || true
+python3 tools/batch_sweep.py 4096 1,2,4,8,16 28:40 > $OUT/batch_sweep_4096.txt 2>&1
+python3 tools/batch_sweep.py 1024 1,4,16,64 28:40 > $OUT/batch_sweep_1024.txt 2>&1
+GPX_LIB_COMPAT=1 python3 tools/timeline2.py 4096 12 15 > $OUT/step_timeline.txt 2>&1 || true
 python3 tools/small_n.py > $OUT/small_n.txt 2>&1 || true
+./tools/peaks > $OUT/peaks.txt 2>&1 || true
+./tools/potrf_stamps > $OUT/potrf_diag_stamps.txt 2>&1 || true
+./tools/dpp_probe > $OUT/dpp_probe.txt 2>&1 || true
+python3 tools/fit_bench.py > $OUT/fit_bench.txt 2>&1 || true
 ls -la $OUT
