@@ -23,7 +23,7 @@ static void run(int nwaves_label) {
     }
   double *dA, *dL, *dW; int* dinfo; unsigned long long* dst;
   hipMalloc(&dA, NB * NB * 8); hipMalloc(&dL, NB * NB * 8); hipMalloc(&dW, NB * NB * 8); hipMalloc(&dinfo, 4);
-  hipMalloc(&dst, 64 * 8);
+  hipMalloc(&dst, 512 * 8); hipMemset(dst, 0, 512 * 8);
   hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dst, sizeof(dst));
   hipMemcpy(dA, a.data(), NB * NB * 8, hipMemcpyHostToDevice);
   hipMemset(dinfo, 0, 4);
@@ -31,7 +31,33 @@ static void run(int nwaves_label) {
   pl.nb = NB; pl.A = dA; pl.lda = NB; pl.L = dL; pl.ldl = NB; pl.W = dW; pl.info = dinfo; pl.col0 = 0;
   for (int rep = 0; rep < 3; ++rep) launch_potrf_diag(nullptr, 0, pl);
   hipDeviceSynchronize();
-  unsigned long long st[64]; hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost);
+  unsigned long long st[512]; hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost);
+#if GPX_POTRF_FLOW
+  printf("NB=%d (dataflow): barrier after %llu cycles, first leaf starts after %llu\n", NB, st[1] - st[0], st[2] - st[0]);
+  for (int jb = 0; jb < NT; ++jb)
+    printf("  stage %d: leaf %llu cycles, hand-over to the next leaf %lld\n", jb, st[3 + 2 * jb] - st[2 + 2 * jb],
+           jb + 1 < NT ? (long long)(st[2 + 2 * (jb + 1)] - st[3 + 2 * jb]) : (long long)(st[2 + 2 * NT] - st[3 + 2 * jb]));
+  for (int w = 1; w < NT; ++w) {
+    printf("  wave %d:", w);
+    for (int jb = 0; jb < w; ++jb) {
+      const unsigned long long* e = st + 64 + w * 32 + jb * 4;
+      printf("  [%d] %lld pre %lld solve %lld upd %lld |", jb, (long long)(e[0] - st[0]), e[3] ? (long long)(e[3] - e[0]) : 0ll,
+             (long long)(e[1] - (e[3] ? e[3] : e[0])), e[2] ? (long long)(e[2] - e[1]) : 0ll);
+    }
+    printf("\n");
+  }
+  for (int w = 1; w < NT; ++w) {
+    const unsigned long long* e = st + 64 + w * 32 + (w - 1) * 4;
+    printf("  F1 wave %d: start %lld, groups final at +%lld +%lld +%lld +%lld, end +%lld\n", w, (long long)(e[0] - st[0]),
+           (long long)(st[320 + w * 8] - e[0]), (long long)(st[320 + w * 8 + 1] - e[0]), (long long)(st[320 + w * 8 + 2] - e[0]),
+           (long long)(st[320 + w * 8 + 3] - e[0]), (long long)(e[1] - e[0]));
+  }
+  printf("  leaf starts:");
+  for (int jb = 0; jb < NT; ++jb) printf(" %llu..%llu", st[2 + 2 * jb] - st[0], st[3 + 2 * jb] - st[0]);
+  printf("\n");
+  printf("  whole kernel %llu cycles (%.1f us @2.4GHz); last wave done %llu\n", st[3 + 2 * NT] - st[0], (st[3 + 2 * NT] - st[0]) / 2400.0,
+         st[2 + 2 * NT] - st[0]);
+#else
   printf("NB=%d: load %llu cycles, first leaf %llu\n", NB, st[1] - st[0], st[2] - st[1]);
   printf("  first leaf: wave0 (potrf) done after %llu cycles, wave1 (inverse) after %llu\n", st[40] - st[1], st[41] - st[1]);
   unsigned long long pa = 0, sh = 0;
@@ -42,6 +68,7 @@ static void run(int nwaves_label) {
   }
   printf("  totals: phaseA %llu slots %llu store %llu ; whole kernel %llu cycles (%.1f us @2.4GHz)\n", pa, sh,
          st[3 + 2 * NT] - st[2 + 2 * NT], st[3 + 2 * NT] - st[0], (st[3 + 2 * NT] - st[0]) / 2400.0);
+#endif
   // correctness spot check
   std::vector<double> l(NB * NB), w(NB * NB);
   hipMemcpy(l.data(), dL, NB * NB * 8, hipMemcpyDeviceToHost);
