@@ -610,7 +610,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   }
   g.zero_info = h->d_info;
   if (h->d_flags) {   // the hand-over flags of the split-panel schedule are cleared by the same launch
-    g.zero_flags = h->d_flags; g.n_zero_flags = (int)(3 * (npad / h->nb));
+    g.zero_flags = h->d_flags; g.n_zero_flags = (int)(4 * (npad / h->nb));
     h->flags_clean = true;
   }
   gram_cost(0, n, &fl, &by);

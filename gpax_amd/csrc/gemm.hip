@@ -39,7 +39,9 @@ struct GemmArgs {
   // ((m / cyc_nb) * cyc_P + cyc_r) * cyc_nb + m % cyc_nb;  cyc_P <= 1: rows are global already
   int cyc_P, cyc_r, cyc_nb;
   unsigned* signal;   // one-pass path: publish the stored tile to an already-resident consumer (see GemmLaunch::signal)
+  int64_t signal_m;   // > 0: only tiles with m0 < signal_m publish
   const unsigned* wait_flag; unsigned wait_count;   // one-pass path: resident start (see GemmLaunch::wait_flag)
+  const unsigned* wait_flag2; unsigned wait_count2;
   int* wait_info;     // set to -7 when the bounded wait gives up
   int tl_id;          // diagnostic timeline build only: launch number (index of this launch's end-time cell)
 };
@@ -107,6 +109,7 @@ __device__ __forceinline__ void batch_offset(GemmArgs& g) {
   g.A += z * g.sA; g.B += z * g.sB; g.C += z * g.sC;
   if (g.signal) g.signal += z * g.s_flag;
   if (g.wait_flag) g.wait_flag += z * g.s_flag;
+  if (g.wait_flag2) g.wait_flag2 += z * g.s_flag;
   if (g.wait_info) g.wait_info += z * g.s_info;
 }
 
@@ -325,11 +328,12 @@ __device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0
   constexpr int NCH = 32 * (KH / 2) / 256;   // 16-B chunks per thread, operand and half
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  if (g.wait_flag) {   // resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
+  if (g.wait_flag || g.wait_flag2) {   // resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
     GEMM_TL(6, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));   // (timeline build) became resident
     if (tid == 0) {
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(g.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) {
+      while ((g.wait_flag && __hip_atomic_load(g.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) ||
+             (g.wait_flag2 && __hip_atomic_load(g.wait_flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count2)) {
         __builtin_amdgcn_s_sleep(4);
         if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) { if (g.wait_info) atomicMin(g.wait_info, -7); break; }
       }
@@ -385,7 +389,7 @@ __device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0
       acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc1, 0, 0, 0);
     }
   }
-  if (g.signal) {
+  if (g.signal && (g.signal_m <= 0 || m0 < g.signal_m)) {
     // publish: write-through (sc1) stores, each wave drains its own, the barrier collects the four waves, ONE
     // lane adds to the agent-scope counter the resident consumer polls
 #pragma unroll
@@ -451,7 +455,8 @@ static void fill_args(GemmArgs& g, const GemmLaunch& L) {
   g.a_upper_tri = L.a_upper_tri;
   g.map_S = 0; g.map_ntj = 0;
   g.sA = L.sA; g.sB = L.sB; g.sC = L.sC; g.s_flag = L.s_flag; g.s_info = L.s_info;
-  g.signal = L.signal; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
+  g.signal = L.signal; g.signal_m = L.signal_m; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
+  g.wait_flag2 = L.wait_flag2; g.wait_count2 = L.wait_count2;
   g.tl_id = -1;
 }
 

@@ -93,9 +93,11 @@ struct GemmLaunch {
   // one-pass (32x32-tile) path: every workgroup that stores a tile publishes it (write-through stores, then one
   // agent-scope add to this counter) for a consumer that is already resident (potrf_diag's resident start)
   unsigned* signal = nullptr;
+  int64_t signal_m = 0;   // > 0: only the tiles whose first row is below signal_m publish and count (the rest store plainly)
   // one-pass path: the kernel is launched early and sleeps until *wait_flag >= wait_count (a producer that is
   // still running publishes its output with write-through stores and then raises the flag)
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;
+  const unsigned* wait_flag2 = nullptr; unsigned wait_count2 = 0;   // a second producer (band kernel: the panel stream's column update)
   int* wait_info = nullptr;   // device int set to -7 if the bounded wait gives up
   // batched hyper-parameter draws (blockIdx.z = draw): per-draw strides in elements (doubles for A/B/C, unsigned for the
   // flags, int for wait_info); 0 = shared by the draws
@@ -223,7 +225,7 @@ struct gpx_handle {
   // P (s_main): the chain -- diagonal blocks; P2 (s_main2): the chain's band kernels; Q (s_far): panels and look-ahead
   // columns; T (s_trail): bulk updates
   hipStream_t s_main = nullptr, s_trail = nullptr, s_far = nullptr, s_main2 = nullptr;
-  unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per draw: flagsU, flagsW, flagsS (nblk each)
+  unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per draw: flagsU, flagsW, flagsS, flagsF (nblk each)
   bool flags_clean = false;        // the flags were cleared by the gram launch of this call (no memset needed)
   hipEvent_t ev_chain2 = nullptr;
   const EpilogueLaunch* epi = nullptr;   // set by fit_predict around the factorisation: the split-panel loop may launch the early half

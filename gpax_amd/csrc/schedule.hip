@@ -27,7 +27,7 @@ int ensure_events(gpx_handle* h, size_t nblk, int nb, int batch) {
   if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
   if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
   if (!h->ev_build) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_build, fl));
-  h->s_flags = 3 * (int64_t)std::max<size_t>(nblk, 64);     // flagsU, flagsW, flagsS
+  h->s_flags = 4 * (int64_t)std::max<size_t>(nblk, 64);     // flagsU, flagsW, flagsS, flagsF
   h->s_mini = 2 * (int64_t)nb * nb;
   GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, h->s_flags * batch));
   GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, h->s_mini * batch));
@@ -190,7 +190,7 @@ struct SplitSchedule {
   hipStream_t P, P2, Q, T;
   bool resident, chain2, fuse_band, kinv, attach, use_dib, lp_flag = false;
   unsigned n_signal;
-  unsigned *flagsU, *flagsW, *flagsS;
+  unsigned *flagsU, *flagsW, *flagsS, *flagsF;
   // "diagonal block in the band kernel" (fused band kernel, ungrouped steps).  The column update of step j used to
   // cover column j+2 from its diagonal block down, behind the wait for the bulk launch that last wrote that column, and
   // the band kernel of step j+1 waited for all of it -- on alternate block columns of the chain-bound middle of the
@@ -202,7 +202,7 @@ struct SplitSchedule {
   // dib[k]: the band kernel of step k has that phase 0 (for panel k-1 on block (k+1,k+1)); band_t[k]: the bulk launch
   // (its step) that last wrote that block and must have finished, or -1.  Both follow from k alone (the grouping is a
   // function of k), so the chain and the side streams agree without talking.
-  std::vector<char> dib;
+  std::vector<char> dib, far_flag;
   std::vector<int64_t> band_t;
   std::vector<hipEvent_t> tev;        // hand-over event of the bulk launch of step k (set when it is launched)
   std::vector<char> t_pending;
@@ -247,6 +247,7 @@ struct SplitSchedule {
     flagsU = h->d_flags;              // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
     flagsW = h->d_flags + nblk;       // [k]: W_k published (S = A W_k^T of step k waits)
     flagsS = h->d_flags + 2 * nblk;   // [k]: tiles of S published (fused band kernel: its second phase waits)
+    flagsF = h->d_flags + 3 * nblk;   // [k]: block row k+2 of column k+1 brought up to date by the panel stream at step k (band kernel of step k+1 waits)
     // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
     // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
     pair_min = kinv ? std::min<int64_t>(h->pair_min, 8) : h->pair_min; quad_min = h->quad_min;
@@ -260,11 +261,11 @@ struct SplitSchedule {
       quad_min = h->batch_group >= 4 ? 2 : 0;
     }
     t_from = nblk;
-    dib.assign((size_t)nblk + 2, 0); band_t.assign((size_t)nblk + 2, -1);
+    dib.assign((size_t)nblk + 2, 0); band_t.assign((size_t)nblk + 2, -1); far_flag.assign((size_t)nblk + 2, 0);
     tev.assign((size_t)nblk, nullptr); t_pending.assign((size_t)nblk, 0);
     if (resident && h->debug_force_timeout) { force_timeout_at = 1; h->debug_force_timeout = 0; }
     if (resident && !h->flags_clean) {
-      if (M.batch == 1) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(3 * nblk) * sizeof(unsigned), P));
+      if (M.batch == 1) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(4 * nblk) * sizeof(unsigned), P));
       else GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(h->s_flags * M.batch) * sizeof(unsigned), P));
     }
     h->flags_clean = false;
@@ -299,6 +300,13 @@ struct SplitSchedule {
       if (use_dib && mr > 0 && ncb > 1 && j - lt == 1) {
         dib[(size_t)(j + 1)] = 1;
         band_t[(size_t)(j + 1)] = (ti >= 0 && j + 2 >= tf) ? ti : -1;
+        // The band kernel of step j+1 learns of this step's column update (column j+1, whose first block row is its
+        // operand) through a device counter instead of a stream-level event wait in front of its launch -- it is then
+        // resident, asleep, when potrf_diag(j+1) ends -- wherever that update runs on the one-pass kernel, i.e. in the
+        // chain-bound steps.  With potrf_diag at 22 us the loop  potrf_diag(j) -> event -> panel -> column update -> event ->
+        // band launch  had become longer than  potrf_diag(j+1) + band: every other gap between two potrf_diag was 20 us
+        // instead of 10.
+        if (fuse_band && j + 2 < nblk && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) far_flag[(size_t)j] = 1;
       }
       if (j == ge) {
         if (nblk - (j + 3 + near) > 0) { ti = j; tf = j + 3 + near; }
@@ -352,7 +360,8 @@ struct SplitSchedule {
     }
     if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], PD));
     if (k + 1 >= nblk) return GPX_OK;
-    if (k >= 1) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_far[(size_t)(k - 1)], 0));   // columns k, k+1 were brought up to date by Q at step k-1
+    const bool far_by_flag = k >= 1 && far_flag[(size_t)(k - 1)] != 0;
+    if (k >= 1 && !far_by_flag) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_far[(size_t)(k - 1)], 0));   // columns k, k+1 were brought up to date by Q at step k-1
     GemmLaunch g = c.panel(k, r0, nb, S, nb, h->s_mini);                                    // S = A_{k+1,k} W_k^T
     if (chain2) { g.wait_flag = flagsW + k; g.wait_count = 1; g.wait_info = h->d_info; }   // W_k arrives in-kernel from potrf_diag(k)
     GemmLaunch u;                                                                           // A_{k+1,k+1} -= S S^T
@@ -370,6 +379,10 @@ struct SplitSchedule {
       z.row_off = 0; z.col_off = 0;
     }
     if (fuse_band) {   // both band kernels (and phase 0) in one launch: S's tiles are handed over through flagsS[k]
+      if (far_by_flag) {
+        g.wait_flag2 = flagsF + (k - 1); g.wait_count2 = (unsigned)((nb / 32) * (nb / 32));
+        if (phase0) { z.wait_flag2 = g.wait_flag2; z.wait_count2 = g.wait_count2; z.wait_info = h->d_info; }
+      }
       g.signal = flagsS + k;
       u.wait_flag = flagsS + k; u.wait_count = (unsigned)((nb / 32) * (nb / 32)); u.wait_info = h->d_info;
       prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * (phase0 ? 3.0 : 2.0) * (double)nb * nb * nb, B * 8.0 * 6.0 * nb * nb);
@@ -449,7 +462,7 @@ struct SplitSchedule {
   }
 
   // Q: columns [cfirst, cfirst+ncol) blocks, rows from block row k+2 (+ skip_blocks) down, -= panels [kfirst, kfirst+npan)
-  int col_update(int64_t k, int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last, int64_t skip_blocks = 0) {
+  int col_update(int64_t k, int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last, int64_t skip_blocks = 0, bool raise_far = false) {
     const int64_t rows = c.rows_at(k), rr = (k + 2 + skip_blocks) * nb, mr = rows - rr;
     if (mr <= 0) return GPX_OK;
     // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
@@ -459,6 +472,7 @@ struct SplitSchedule {
     GemmLaunch t = c.update(rr, mr, cfirst, ncol, kfirst, npan, !(h->la_rows > 0 && rows - (k + 2) * nb >= h->la_rows));
     if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
     if (lp_flag && k == nblk - 2 && cfirst == nblk - 1) t.signal = flagsS + (nblk - 1);   // the last border panel waits for these tiles (chain stream)
+    if (raise_far) { t.signal = flagsF + k; t.signal_m = nb; }   // the band kernel of step k+1 waits for the tiles of the first block row
     t.role = 1;
     double entries = 0.0;
     for (int64_t cc = cfirst; cc < cfirst + ncol; ++cc)
@@ -491,7 +505,7 @@ struct SplitSchedule {
       if (dib[(size_t)(k + 1)]) {
         // column k+1 alone carries the hand-over to the chain; column k+2 from BELOW its diagonal block, behind the
         // wait for the bulk launch (the band kernel of step k+1 applies panel k to that block itself)
-        GPX_RET(col_update(k, k + 1, 1, k, 1, true));
+        GPX_RET(col_update(k, k + 1, 1, k, 1, true, 0, far_flag[(size_t)k] != 0));
         if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
         far_attached = true;   // recorded (or attached) already: not again behind the second column
         if (col2_in_bulk) GPX_RET(q_wait_for_bulk());
