@@ -1,4 +1,4 @@
-// potrf.hip -- LDS-resident factorisation of one diagonal block (gfx950).
+// potrf.hip -- LDS-resident factorisation of one diagonal block (gfx950), as a dataflow kernel.
 //
 // One workgroup takes the NB x NB diagonal block A_kk of the right-looking blocked
 // Cholesky (the `cho_factor` of gpax/gp.py:296 / the Cholesky inside
@@ -9,17 +9,14 @@
 // so that every other step of the factorisation (panel solve, posterior solves) is a
 // plain MFMA GEMM against W_k instead of a triangular solve.
 //
-// Per 16-column sub-panel jb:
-//   leaf   one wave factors the 16x16 diagonal tile with one matrix ROW per lane: the
-//          pivot column / pivot row are broadcast with DPP `row_newbcast` (no LDS, no
-//          readlane), and the same sweep forward-substitutes the identity, giving
-//          inv(L_jj) for free;
-//   phase A  (all waves, one tile each)  L_ib,jb = A_ib,jb * inv(L_jj)^T        [4 MFMA]
-//            and row jb of W:  W_jb,cb = -inv(L_jj) * sum_kb L_jb,kb W_kb,cb   [4(jb-cb)+4 MFMA]
-//   phase B  trailing tiles  A_ib,lb -= L_ib,jb * L_lb,jb^T                     [4 MFMA]
-// Tiles live un-padded in LDS (2 KiB each; 36 + 36 tiles = 144 KiB at NB = 128) with the
-// XOR swizzle  elem(r,c) -> r*16 + (c ^ (r & 14)), which makes both the row-fragment
-// and the column-fragment ds_read_b64 patterns of the f64 MFMA conflict-free.
+// The 16 x 16 leaf factors a diagonal tile with one matrix ROW per lane: the pivot column / pivot row are
+// broadcast with DPP `row_newbcast` (no LDS, no readlane).  One wave issues one fp64 instruction every ~7.2 cycles
+// whatever the EXEC mask (tools/dpp_probe), so the leaf is issue-bound at ~3.0-3.6k cycles and everything else in this
+// file is arranged to keep the NEXT leaf's input ready when the current one ends (see "Dataflow form" below).
+// Off-diagonal tiles live in LDS with the XOR swizzle  elem(r,c) -> r*16 + (c ^ (r & 14)), which makes both the
+// row-fragment and the column-fragment ds_read_b64 patterns of the f64 MFMA conflict-free.
+// (Round 2 retired the barrier-phased form of this kernel -- leaf | sub-panel solve by inv(L_jj) | rank-16 update, two
+// workgroup barriers per 16 columns, 29 us per 128 x 128 block -- for the dataflow form, 22 us.)
 
 #include <type_traits>
 
@@ -33,50 +30,19 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// broadcast lane L of every 16-lane row to the whole row (DPP row_newbcast, gfx90a+)
-template <int L>
-__device__ __forceinline__ double row_bcast(double x) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x150 + L, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x150 + L, 0xf, 0xf, false);
-  return __hiloint2double(hi, lo);
-}
-
-// 64-bit form (one v_mov_b64_dpp)
+// broadcast lane L of every 16-lane row to the whole row (DPP row_newbcast, one v_mov_b64_dpp)
 template <int L>
 __device__ __forceinline__ double row_bcast64(double x) {
   return __builtin_amdgcn_update_dpp(0.0, x, 0x150 + L, 0xf, 0xf, false);
 }
 
-// acc += row_newbcast<L>(src) * mul  as ONE instruction (v_fmac_f64_dpp: 7.2 cycles issued from one
-// wave, the same as a plain v_fma_f64; a v_mov_b64_dpp + v_fma_f64 pair costs 13.6 -- tools/dpp_probe).
-// hipcc neither pads hazards inside an asm string nor knows this is a DPP read, so the statements
-// are `volatile` (they keep the program order written here) and the one hazard that order leaves
-// open -- a DPP read needs 2 wait states after a VALU write of its source VGPR -- is closed by
-// dpp_fence() before each group instead of an s_nop per instruction (an s_nop 1 costs ~8 cycles here).
-template <int L>
-__device__ __forceinline__ void fmac_bcast(double& acc, double src, double mul) {
-  asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-               : "+v"(acc)
-               : "v"(src), "v"(mul), "i"(L));
-}
+// The DPP instructions below are written as `asm volatile` (hipcc neither pads hazards inside an asm string nor knows
+// they are DPP reads): they keep the program order written here, and the one hazard that order leaves open -- a DPP
+// read needs 2 wait states after a VALU write of its source VGPR -- is closed by dpp_fence() before each group instead
+// of an s_nop per instruction (an s_nop 1 costs ~8 cycles here).  v_fmac_f64_dpp: 7.2 cycles issued from one wave, the
+// same as a plain v_fma_f64; a v_mov_b64_dpp + v_fma_f64 pair costs 13.6 (tools/dpp_probe).
 // Orders every earlier write of `x` before the statement and gives 2 wait states after it.
 __device__ __forceinline__ void dpp_fence(double& x) { asm volatile("s_nop 1" : "+v"(x)); }
-
-// 1/sqrt(d) and sqrt(d) from v_rsq_f64 (measured 2^-24.2 relative accuracy on gfx950,
-// tools/rsq_probe) and ONE cubic (Halley) step:  y <- y (1 + e/2 + 3e^2/8),  e = 1 - d y^2,
-// error O(e^3) ~ 1e-22 -> ~1 ulp after rounding.  Dependency depth 4 fp64 ops after the rsq:
-// this chain is the critical path of the whole factorisation (one per matrix column).
-// No denormal rescaling: pivots here are O(1e-6 .. 1e3).
-__device__ __forceinline__ void sqrt_rsqrt(double d, double& s, double& rinv) {
-  const double y = __builtin_amdgcn_rsq(d);
-  const double t = d * y;
-  const double e = fma(-t, y, 1.0);
-  const double c = fma(0.375, e, 0.5);
-  const double ye = y * e;
-  rinv = fma(ye, c, y);
-  s = d * rinv;
-}
 
 __device__ __forceinline__ int tix(int ib, int jb) { return ib * (ib + 1) / 2 + jb; }
 __device__ __forceinline__ int eix(int r, int c) { return r * 16 + (c ^ (r & 14)); }
@@ -112,88 +78,8 @@ __device__ __forceinline__ void tile_trsm(double* At, const double* Wd, int fr, 
   for (int r = 0; r < 4; ++r) At[eix(fk + 4 * r, fr)] = acc0[r] + acc1[r];
 }
 
-// C -= A * B^T :  A[i][k] = -Ap[i][k], B[k][j] = Bp[j][k]
-__device__ __forceinline__ void tile_syrk(double* Cp, const double* Ap, const double* Bp, int fr, int fk) {
-  v4d acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) acc0[r] = Cp[eix(fk + 4 * r, fr)];
-  acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[eix(fr, fk)], Bp[eix(fr, fk)], acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[eix(fr, 4 + fk)], Bp[eix(fr, 4 + fk)], acc1, 0, 0, 0);
-  acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[eix(fr, 8 + fk)], Bp[eix(fr, 8 + fk)], acc0, 0, 0, 0);
-  acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Ap[eix(fr, 12 + fk)], Bp[eix(fr, 12 + fk)], acc1, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) Cp[eix(fk + 4 * r, fr)] = acc0[r] + acc1[r];
-}
-
-// Two independent C -= A * B^T tile updates in one instruction stream: the LDS-read -> MFMA -> LDS-write
-// chain of a single tile is latency bound (~1.5k cycles), two interleaved chains hide each other.
-__device__ __forceinline__ void tile_syrk2(double* C0, const double* A0, const double* B0, double* C1, const double* A1,
-                                           const double* B1, int fr, int fk) {
-  v4d p0, p1, q0 = {0.0, 0.0, 0.0, 0.0}, q1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { p0[r] = C0[eix(fk + 4 * r, fr)]; p1[r] = C1[eix(fk + 4 * r, fr)]; }
-  double a0[4], b0[4], a1[4], b1[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    a0[s] = -A0[eix(fr, 4 * s + fk)]; b0[s] = B0[eix(fr, 4 * s + fk)];
-    a1[s] = -A1[eix(fr, 4 * s + fk)]; b1[s] = B1[eix(fr, 4 * s + fk)];
-  }
-  p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], b0[0], p0, 0, 0, 0);
-  p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], b1[0], p1, 0, 0, 0);
-  q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], b0[1], q0, 0, 0, 0);
-  q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], b1[1], q1, 0, 0, 0);
-  p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[2], b0[2], p0, 0, 0, 0);
-  p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[2], b1[2], p1, 0, 0, 0);
-  q0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[3], b0[3], q0, 0, 0, 0);
-  q1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[3], b1[3], q1, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { C0[eix(fk + 4 * r, fr)] = p0[r] + q0[r]; C1[eix(fk + 4 * r, fr)] = p1[r] + q1[r]; }
-}
-
-// W tile (jb, cb), cb < jb:  T = sum_{kb=cb}^{jb-1} L_jb,kb * W_kb,cb ;  W_jb,cb = -inv(L_jj) * T
-__device__ __forceinline__ void tile_winv(double* Lt, double* Wt, int jb, int cb, int fr, int fk) {
-  double* Tp = Wt + tix(jb, cb) * 256;
-  const double* Wd = Wt + tix(jb, jb) * 256;
-  v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-  for (int kb = cb; kb < jb; ++kb) {
-    const double* Lp = Lt + tix(jb, kb) * 256;
-    const double* Wp = Wt + tix(kb, cb) * 256;
-    // A[i][k] = L_jb,kb[i][k] , B[k][j] = W_kb,cb[k][j]
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[eix(fr, fk)], Wp[eix(fk, fr)], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[eix(fr, 4 + fk)], Wp[eix(4 + fk, fr)], acc1, 0, 0, 0);
-    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[eix(fr, 8 + fk)], Wp[eix(8 + fk, fr)], acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[eix(fr, 12 + fk)], Wp[eix(12 + fk, fr)], acc1, 0, 0, 0);
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) Tp[eix(fk + 4 * r, fr)] = acc0[r] + acc1[r];
-  // same-wave LDS round trip (LDS operations of one wave execute in order): T as the B operand
-  v4d a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-  a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[eix(fr, fk)], Tp[eix(fk, fr)], a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[eix(fr, 4 + fk)], Tp[eix(4 + fk, fr)], a1, 0, 0, 0);
-  a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[eix(fr, 8 + fk)], Tp[eix(8 + fk, fr)], a0, 0, 0, 0);
-  a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[eix(fr, 12 + fk)], Tp[eix(12 + fk, fr)], a1, 0, 0, 0);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) Tp[eix(fk + 4 * r, fr)] = a0[r] + a1[r];
-}
-
-// ---- 16x16 leaf, split over TWO waves that sit on different SIMDs -------------------------
-// One matrix row per lane (the 4 DPP rows of a wave work redundantly); pivot column / pivot row
-// are broadcast by DPP.  A single wave issues one fp64 instruction every ~7.2 cycles, so the leaf
-// is issue-bound: wave 0 runs only the Cholesky recurrence (the critical path of the whole
-// factorisation) and publishes each finished column through LDS; wave 1 follows behind and
-// forward-substitutes the identity with them, giving inv(L_jj).
-//
-// Hand-off area (LDS, 16 columns x 40 doubles; the 4 redundant DPP rows store identical values to
-// the same slots, so no store is predicated): per column j   [0..15] l_ij by row   [16..31] 1/l_jj
-// (16 copies)   [32..39] 16 x int epoch; plus one always-zero double behind the columns.  LDS executes a wave's DS
-// instructions in order, so a reader that sees a group's epoch sees the group's data.  Epochs increase monotonically over the
-// kernel (leaf jb, column j -> 16 jb + j + 1): nothing is ever reset.
-#define LEAF_COL_DOUBLES 40
-#define LEAF_ZERO_SLOT (16 * LEAF_COL_DOUBLES)
-#define LEAF_SHARE_DOUBLES (16 * LEAF_COL_DOUBLES + 2)
-
-// wave 1 consumes the columns in groups {0-3} {4-7} {8-11} {12,13} {14} {15}: one LDS round trip per
-// group, short groups at the end so that it finishes right behind wave 0
+// readers consume the leaf's columns in groups {0-3} {4-7} {8-11} {12,13} {14} {15}: one LDS round trip per
+// group, short groups at the end so that they finish right behind the leaf
 __host__ __device__ constexpr int leaf_group_start(int j) { return j < 12 ? (j & ~3) : (j < 14 ? 12 : j); }
 __host__ __device__ constexpr int leaf_group_size(int j) { return j < 12 ? 4 : (j < 14 ? 2 : 1); }
 __host__ __device__ constexpr bool leaf_group_end(int j) { return j == leaf_group_start(j) + leaf_group_size(j) - 1; }
@@ -218,169 +104,12 @@ __device__ __forceinline__ void fnmac_bcast(double& acc, double src, double mul)
                : "v"(src), "v"(mul), "i"(L));
 }
 
-// wave 0: L_jj.  No predication at all: finished rows (i <= j) only ever corrupt their own
-// above-diagonal entries, which are don't-care; lane j gets l_jj = d * rinv from the same multiply.
-__device__ __forceinline__ void leaf_potrf(double* Ld, double* share, int lane, int base_epoch, int* info,
-                                           int gcol0) {
-  const int i = lane & 15;
-  double a[16];
-  // eix(i, c) keeps even/odd column pairs adjacent (the XOR mask is even): 8 x 16-B accesses per row
-#pragma unroll
-  for (int c = 0; c < 16; c += 2) {
-    const v2d v = *reinterpret_cast<const v2d*>(Ld + eix(i, c));
-    a[c] = v.x; a[c + 1] = v.y;
-  }
-  double d = row_bcast64<0>(a[0]);                   // pivot a_00
-  static_for<0, 16>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    // 1/sqrt(d): v_rsq_f64 + one cubic step (see sqrt_rsqrt)
-    const double y = __builtin_amdgcn_rsq(d);
-    const double t = d * y;
-    const double e = fma(-t, y, 1.0);
-    const double cc = fma(0.375, e, 0.5);
-    const double ye = y * e;
-    const double rinv = fma(ye, cc, y);
-    double l = a[j] * rinv;                          // column j of L; lane j: d * rinv = l_jj
-    a[j] = l;
-    // publish column j (l per lane, then 1/l_jj per lane); its epoch only at the end of a
-    // consumer group (leaf_group_end)
-    share[j * LEAF_COL_DOUBLES + i] = l;
-    share[j * LEAF_COL_DOUBLES + 16 + i] = rinv;
-    if constexpr (leaf_group_end(j)) {
-      asm volatile("" ::: "memory");
-      reinterpret_cast<int*>(share + j * LEAF_COL_DOUBLES + 32)[i] = base_epoch + j + 1;
-    }
-    dpp_fence(l);                                    // l was just written by a VALU multiply
-    // rank-1 update a_ic -= l_ij * l_cj (c > j).  c = j+1 first: it is the next pivot, whose
-    // broadcast is issued as soon as the DPP-read hazard allows (two fmacs later).
-    if constexpr (j + 1 < 16) fnmac_bcast<j + 1>(a[j + 1], l, l);
-    if constexpr (j + 2 < 16) fnmac_bcast<j + 2>(a[j + 2], l, l);
-    if constexpr (j + 3 < 16) fnmac_bcast<j + 3>(a[j + 3], l, l);
-    if constexpr (j + 3 < 16) d = pivot_bcast<j + 1>(a[j + 1]);
-    else if constexpr (j + 1 < 16) d = pivot_bcast_padded<j + 1>(a[j + 1]);
-    static_for<j + 4, 16>([&](auto C) {
-      constexpr int c = decltype(C)::value;
-      fnmac_bcast<c>(a[c], l, l);
-    });
-  });
-  // LAPACK-style info: the first non-positive (or NaN) pivot shows as the first diagonal entry
-  // that is not a positive number (NaN propagates to every later pivot)
-  const unsigned long long bad = __ballot(!(a[i] > 0.0)) & 0xffffull;
-  if (bad && lane == 0 && *info == 0) *info = gcol0 + __ffsll((long long)bad);
-  // entries above the diagonal are don't-care here; the write-out phase zeroes them
-  if (lane < 16) {
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-      v2d v; v.x = a[c]; v.y = a[c + 1];
-      *reinterpret_cast<v2d*>(Ld + eix(i, c)) = v;
-    }
-  }
-}
-
-// One LDS round trip for a group of CNT columns starting at J0: the group's epoch, and (l_i, 1/l_jj)
-// of every column (loads and their wait in ONE asm statement: hipcc does not count loads inside asm).
-// la[] are per-lane byte addresses of l_ij, already redirected to the always-zero slot for finished
-// rows (i <= j), so the multiplier of a finished row is exactly 0 with no select.
-template <int J0, int CNT>
-__device__ __forceinline__ void fetch_group(unsigned lds_base, unsigned ep_base, const unsigned (&la)[16], int& epoch,
-                                            double (&l)[4], double (&r)[4]) {
-  constexpr int B = LEAF_COL_DOUBLES * 8;
-  if constexpr (CNT == 4) {
-    asm volatile(
-        "ds_read_b32 %0, %10 offset:%15\n\t"
-        "ds_read_b64 %1, %11\n\tds_read_b64 %2, %9 offset:%16\n\t"
-        "ds_read_b64 %3, %12\n\tds_read_b64 %4, %9 offset:%17\n\t"
-        "ds_read_b64 %5, %13\n\tds_read_b64 %6, %9 offset:%18\n\t"
-        "ds_read_b64 %7, %14\n\tds_read_b64 %8, %9 offset:%19\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(epoch), "=&v"(l[0]), "=&v"(r[0]), "=&v"(l[1]), "=&v"(r[1]), "=&v"(l[2]), "=&v"(r[2]), "=&v"(l[3]), "=&v"(r[3])
-        : "v"(lds_base), "v"(ep_base), "v"(la[J0]), "v"(la[J0 + 1]), "v"(la[J0 + 2]), "v"(la[J0 + 3]), "i"((J0 + 3) * B),
-          "i"(J0 * B + 128), "i"((J0 + 1) * B + 128), "i"((J0 + 2) * B + 128), "i"((J0 + 3) * B + 128)
-        : "memory");
-  } else if constexpr (CNT == 2) {
-    asm volatile(
-        "ds_read_b32 %0, %6 offset:%9\n\t"
-        "ds_read_b64 %1, %7\n\tds_read_b64 %2, %5 offset:%10\n\t"
-        "ds_read_b64 %3, %8\n\tds_read_b64 %4, %5 offset:%11\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(epoch), "=&v"(l[0]), "=&v"(r[0]), "=&v"(l[1]), "=&v"(r[1])
-        : "v"(lds_base), "v"(ep_base), "v"(la[J0]), "v"(la[J0 + 1]), "i"((J0 + 1) * B), "i"(J0 * B + 128), "i"((J0 + 1) * B + 128)
-        : "memory");
-  } else {
-    asm volatile(
-        "ds_read_b32 %0, %4 offset:%6\n\t"
-        "ds_read_b64 %1, %5\n\tds_read_b64 %2, %3 offset:%7\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(epoch), "=&v"(l[0]), "=&v"(r[0])
-        : "v"(lds_base), "v"(ep_base), "v"(la[J0]), "i"(J0 * B), "i"(J0 * B + 128)
-        : "memory");
-  }
-}
-
-// wave 1: inv(L_jj) by forward substitution of the identity on the UNSCALED rows u_i = l_ii w_i:
-//   u_i -= (l_ij / l_jj) u_j  (i > j);  w_i = u_i / l_ii once at the end.
-// Entries above the diagonal are never touched (updates of row i only reach columns c <= j < i),
-// so they stay exactly 0 and nothing is predicated.
-__device__ __forceinline__ void leaf_winv(double* Wd, double* share, int lane, int base_epoch) {
-  const int i = lane & 15;
-  // per-lane LDS byte addresses (the low 32 bits of a generic LDS pointer are the LDS offset)
-  const unsigned lds_base = (unsigned)(uintptr_t)(share + i);   // l_i of column 0; +128 B: 1/l_jj copy i
-  const unsigned ep_base = (unsigned)(uintptr_t)(share + 32) + 4 * i;   // epoch copy i of column 0
-  const unsigned zero_addr = (unsigned)(uintptr_t)(share + LEAF_ZERO_SLOT);
-  unsigned la[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) la[j] = (i > j) ? lds_base + j * (LEAF_COL_DOUBLES * 8) : zero_addr;
-  double w[16];
-#pragma unroll
-  for (int c = 0; c < 16; ++c) w[c] = (c == i) ? 1.0 : 0.0;
-  // hipcc may sink these VALU initialisations down to the first use, which is a DPP read inside an
-  // asm it cannot see into: pin them here, two wait states ahead of every DPP read
-  asm volatile("s_nop 1"
-               : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]),
-                 "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15]));
-  double gl[4], gr[4];
-  static_for<0, 16>([&](auto J) {
-    constexpr int j = decltype(J)::value;
-    constexpr int j0 = leaf_group_start(j), cnt = leaf_group_size(j);
-    if constexpr (j == j0) {
-      int epoch;
-      fetch_group<j0, cnt>(lds_base, ep_base, la, epoch, gl, gr);
-      // Wave 0 publishes in order and never waits on this wave, so the group's last epoch arrives;
-      // the spin bound only guards against a hang if that ever stopped being true.
-      for (int spin = 0; __any(epoch != base_epoch + j0 + cnt) && spin < (1 << 20); ++spin) {
-        __builtin_amdgcn_s_sleep(1);
-        fetch_group<j0, cnt>(lds_base, ep_base, la, epoch, gl, gr);
-      }
-    }
-    double m = gl[j - j0] * gr[j - j0];              // l_ij / l_jj (exactly 0 for finished rows)
-    // DPP source of the group is w[c], last written by column j-1's group; only the first columns
-    // have fewer than two instructions in between
-    if constexpr (j <= 2) dpp_fence(w[0]);
-    static_for<0, j + 1>([&](auto C) {
-      constexpr int c = decltype(C)::value;
-      fnmac_bcast<j>(w[c], w[c], m);                 // w[c] -= bcast_j(w[c]) * (l_ij / l_jj)
-    });
-  });
-  const double my_rinv = share[i * LEAF_COL_DOUBLES + 16 + i];   // 1 / l_ii (all columns are published by now)
-  if (lane < 16) {
-#pragma unroll
-    for (int c = 0; c < 16; c += 2) {
-      v2d v; v.x = w[c] * my_rinv; v.y = w[c + 1] * my_rinv;
-      *reinterpret_cast<v2d*>(Wd + eix(i, c)) = v;
-    }
-  }
-}
-
 // one wave writes LDS tile (ib, jb) of `tiles` to the global matrix `dst` (leading dimension ld);
 // for a diagonal tile of L the don't-care entries above the diagonal become zeros
-// W_k is published with plain stores and ONE agent-scope release per wave in front of the flag (GPX_W_THROUGH 0):
-// write-through stores of every W tile (GPX_W_THROUGH 1) lengthened the kernel from 29 to 36 us.
-#ifndef GPX_W_THROUGH
-#define GPX_W_THROUGH 0
-#endif
-// `through`: write-through (agent-scope) stores, for a block that is handed to an already-resident consumer
+// W_k is published with plain stores and ONE agent-scope release per wave in front of the flag (write-through stores
+// of every W tile lengthened the kernel by a quarter).
 __device__ __forceinline__ void store_tile(const double* tiles, double* dst, int64_t ld, int ib, int jb, int lane,
-                                           bool zero_upper_of_diag, bool through = false) {
+                                           bool zero_upper_of_diag) {
   const int r = lane >> 2, c4 = (lane & 3) * 4;
   const double* src = tiles + tix(ib, jb) * 256;
   double* out = dst + (int64_t)(ib * 16 + r) * ld + jb * 16 + c4;
@@ -390,19 +119,10 @@ __device__ __forceinline__ void store_tile(const double* tiles, double* dst, int
     v[q] = src[eix(r, c4 + q)];
     if (zero_upper_of_diag && ib == jb && c4 + q > r) v[q] = 0.0;
   }
-  if (through) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) __hip_atomic_store(&out[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
-  }
 #pragma unroll
   for (int q = 0; q < 4; ++q) out[q] = v[q];
 }
 
-// Schedule (NT = NB/16 sub-panels; wave 0 carries the critical path):
-//   leaf(0) | for jb: phase A (sub-panel solve, all waves) | { wave 0: update tile (jb+1,jb+1),
-//   leaf(jb+1) }  ||  { other waves: the rest of the rank-16 update, then row jb of W }
-// so the in-block trailing update and the whole inversion hide behind the leaf chain.
 #ifdef GPX_TIMELINE
 __device__ unsigned long long* g_tl_potrf;
 void tl_set_potrf(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_tl_potrf), &p, sizeof(p)); }
@@ -420,183 +140,9 @@ void tl_set_potrf(unsigned long long* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_
 #define POTRF_TL(kind, a) do { } while (0)
 #endif
 
-#ifndef POTRF_WAVES_128
-#define POTRF_WAVES_128 8   // waves of the 128-wide kernel.  12 / 16 waves spread the shadow work thinner but spill (168 / 128-register budgets) and crowd the leaf wave's SIMD: 1.77 -> 1.94 / 2.13 ms per N = 4096 step
-#endif
-template <int NB, int NWAVES>
-__device__ __forceinline__ void potrf_block(const double* A, int64_t lda, double* __restrict__ L, int64_t ldl,
-                                            double* __restrict__ W, int* info, int col0, const unsigned* wait_flag,
-                                            unsigned wait_count, unsigned* done_flag, unsigned long long wait_ticks, double* sm) {
-  constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
-  double* Lt = sm;
-  double* Wt = sm + NTRI * 256;
-  double* sh = sm + 2 * NTRI * 256;   // leaf hand-off area
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int fr = lane & 15, fk = lane >> 4;
-  // Resident start (split-panel schedule): the kernel is launched a whole step early, so that it already owns a
-  // CU (it needs all of its LDS, and behind a saturating bulk update a freshly launched one waits 20-30 us for a
-  // CU to drain), and sleeps here until the `wait_count` workgroups of the preceding A_kk -= S S^T kernel have
-  // published their tiles (write-through stores + an agent-scope counter, gemm.hip).  One lane polls, relaxed;
-  // ONE agent-scope acquire after the match drops this CU's stale lines; then the barrier releases the loads.
-  // The spin is bounded (wait_ticks of s_memrealtime, 0.25 s by default): on a timeout the block reports info = -7 and
-  // carries on (the host discards the results and repeats the call with kernel-boundary hand-overs).
-  if (wait_flag) {
-    POTRF_TL(5, col0);
-    if (tid == 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_count) {
-        __builtin_amdgcn_s_sleep(8);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) { atomicMin(info, -7); break; }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-  }
-  POTRF_TL(1, col0);
-  GPX_STAMP(0);
-  for (int t = tid; t < LEAF_SHARE_DOUBLES; t += NWAVES * 64) sh[t] = 0.0;   // epochs start at 0
-
-  // ---- load the lower tiles of A_kk.  Wave 0 fetches only the first diagonal tile (all the first
-  // leaf needs), waves 2.. fetch the rest; every global load is issued BEFORE the barrier and the bulk
-  // of them lands while the first leaf is already running (plain loads stay in flight across
-  // s_barrier).  Wave 1 (the inverse half of the leaf) loads nothing.
-  constexpr int LW = NWAVES - 2;                         // loader waves
-  constexpr int TPL = (NTRI - 1 + LW - 1) / LW;          // tiles per loader wave
-  {
-    const int r = lane >> 2, c4 = (lane & 3) * 4;
-    double v[TPL][4];
-    if (wave == 0) {
-      const double* src = A + (int64_t)r * lda + c4;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[0][q] = src[q];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Lt[eix(r, c4 + q)] = v[0][q];
-    } else if (wave >= 2) {
-#pragma unroll
-      for (int u = 0; u < TPL; ++u) {
-        const int t = 1 + (wave - 2) + u * LW;
-        if (t < NTRI) {
-          int ib = 0, jb = t;
-          while (jb > ib) { jb -= ib + 1; ++ib; }
-          const double* src = A + (int64_t)(ib * 16 + r) * lda + jb * 16 + c4;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[u][q] = src[q];
-        }
-      }
-    }
-    __syncthreads();   // hand-off area zeroed, tile (0,0) in LDS
-    GPX_STAMP(1);
-    if (wave == 0) { leaf_potrf(Lt + tix(0, 0) * 256, sh, lane, 0, info, col0); GPX_STAMP(40); }
-    else if (wave == 1) { leaf_winv(Wt + tix(0, 0) * 256, sh, lane, 0); GPX_STAMP_T(41, 64); }
-    else {
-#pragma unroll
-      for (int u = 0; u < TPL; ++u) {
-        const int t = 1 + (wave - 2) + u * LW;
-        if (t < NTRI) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) Lt[t * 256 + eix(r, c4 + q)] = v[u][q];
-        }
-      }
-      // zeros above the diagonal of the L block and of W (nothing depends on them)
-      for (int t = wave - 2; t < NT * NT; t += LW) {
-        const int ib = t / NT, jb = t % NT;
-        if (jb > ib) {
-          double* ldst = L + (int64_t)(ib * 16 + r) * ldl + jb * 16 + c4;
-          double* wdst = W + (int64_t)(ib * 16 + r) * NB + jb * 16 + c4;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            ldst[q] = 0.0;
-            wdst[q] = 0.0;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-#pragma unroll 1
-  for (int jb = 0; jb < NT; ++jb) {
-    GPX_STAMP(2 + 2 * jb);
-    // ---- phase A: sub-panel solve, tiles (ib, jb), ib > jb; wave 0 takes (jb+1, jb)
-    {
-      const double* Wd = Wt + tix(jb, jb) * 256;
-      for (int ib = jb + 1 + wave; ib < NT; ib += NWAVES) tile_trsm(Lt + tix(ib, jb) * 256, Wd, fr, fk);
-    }
-    __syncthreads();
-    GPX_STAMP(3 + 2 * jb);
-    // ---- shadow slot: critical path on wave 0, everything else on the other waves
-    if (jb + 1 < NT) {
-      if (wave == 0) {
-        double* Cp = Lt + tix(jb + 1, jb + 1) * 256;
-        const double* Ap = Lt + tix(jb + 1, jb) * 256;
-        tile_syrk(Cp, Ap, Ap, fr, fk);
-        leaf_potrf(Cp, sh, lane, (jb + 1) * 16, info, col0 + (jb + 1) * 16);
-      } else if (wave == 1) {
-        leaf_winv(Wt + tix(jb + 1, jb + 1) * 256, sh, lane, (jb + 1) * 16);
-      } else {
-        const int tn = NT - 1 - jb;
-        const int ntiles = tn * (tn + 1) / 2;
-        // rank-16 update tiles q = 1 .. ntiles-1 (q = 0 is wave 0's), two per wave and iteration
-        auto tile_of = [&](int q, double*& Cp, const double*& Ap, const double*& Bp) {
-          int ib2 = 0, q2 = q;
-          while (q2 > ib2) { q2 -= ib2 + 1; ++ib2; }
-          const int ib = jb + 1 + ib2, lb = jb + 1 + q2;
-          Cp = Lt + tix(ib, lb) * 256; Ap = Lt + tix(ib, jb) * 256; Bp = Lt + tix(lb, jb) * 256;
-        };
-        constexpr int SW = NWAVES - 2;   // waves sharing the shadow work
-        for (int q = 1 + 2 * (wave - 2); q < ntiles; q += 2 * SW) {
-          double *C0, *C1; const double *A0, *B0, *A1, *B1;
-          tile_of(q, C0, A0, B0);
-          if (q + 1 < ntiles) {
-            tile_of(q + 1, C1, A1, B1);
-            tile_syrk2(C0, A0, B0, C1, A1, B1, fr, fk);
-          } else {
-            tile_syrk(C0, A0, B0, fr, fk);
-          }
-        }
-        for (int cb = wave - 2; cb < jb; cb += SW) tile_winv(Lt, Wt, jb, cb, fr, fk);   // row jb of W: off the critical path
-        // write out what is final: column jb of L (after phase A) and row jb-1 of W (previous slot)
-        for (int q = wave - 2; q < NT; q += NWAVES - 2) {
-          if (q < NT - jb) store_tile(Lt, L, ldl, jb + q, jb, lane, true);
-          else if (jb >= 1) store_tile(Wt, W, NB, jb - 1, q - (NT - jb), lane, false, GPX_W_THROUGH && done_flag != nullptr);
-        }
-      }
-    } else {
-      // last row of W: nothing left to hide behind, all waves share it
-      for (int cb = wave; cb < jb; cb += NWAVES) tile_winv(Lt, Wt, jb, cb, fr, fk);
-    }
-    __syncthreads();
-  }
-
-  GPX_STAMP(2 + 2 * NT);
-  // ---- write out the remainder: the last L tile and the last two rows of W (everything else went
-  // out in the shadow slots)
-  {
-    for (int q = wave; q < 2 * NT; q += NWAVES) {
-      if (q == 0) store_tile(Lt, L, ldl, NT - 1, NT - 1, lane, true);
-      else if (q <= NT) store_tile(Wt, W, NB, NT - 1, q - 1, lane, false, GPX_W_THROUGH && done_flag != nullptr);
-      else if (NT >= 2) store_tile(Wt, W, NB, NT - 2, q - NT - 1, lane, false, GPX_W_THROUGH && done_flag != nullptr);
-    }
-  }
-  GPX_STAMP(3 + 2 * NT);
-  POTRF_TL(2, col0);
-  // publish W_k to the already-resident S = A W_k^T kernel: every wave drains its (write-through) stores, the
-  // barrier collects the waves, one lane raises the flag
-  if (done_flag) {
-#if GPX_W_THROUGH
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // plain stores above: write this XCD's dirty lines back
-#endif
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(done_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
 
 // =====================================================================================================
-// Dataflow form of the same factorisation (GPX_POTRF_FLOW, the default): no workgroup barrier inside the
+// Dataflow form: no workgroup barrier inside the
 // block, no phase structure.  Wave r OWNS block row r of the 16 x 16 tiling (NT = NB/16 waves):
 //
 //   stage jb < r   follower: while wave jb runs the leaf of tile (jb,jb) and publishes its columns, wave r
@@ -619,9 +165,6 @@ __device__ __forceinline__ void potrf_block(const double* A, int64_t lda, double
 // The leaf publishes IN PLACE: column j of L_jj overwrites column j of the tile.  Every stage has its own area, so a
 // follower may lag as far as it likes.  Synchronisation is by LDS words only: the stage epochs and one "tile final" flag
 // per L tile; every wait is bounded (info = -8 on exhaustion: a logic error, never seen).
-#ifndef GPX_POTRF_FLOW
-#define GPX_POTRF_FLOW 1
-#endif
 #define FLOW_SPIN_MAX (1 << 22)
 #define DT_RINV 256
 #define DT_ZERO 272
@@ -1074,20 +617,13 @@ struct PotrfArgs {
 
 template <int NB, int NWAVES>
 __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(PotrfArgs p) {
-  constexpr int NTRI = (NB / 16) * (NB / 16 + 1) / 2;
+  constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
+  static_assert(NWAVES == NT, "potrf_diag: one wave per block row");
+  __shared__ double sm[NT * NT * 256 + NT * DT_STRIDE + (NTRI + NT) / 2 + 2];
   const int64_t z = blockIdx.x;
-#if GPX_POTRF_FLOW
-  static_assert(NWAVES == NB / 16, "dataflow potrf_diag: one wave per block row");
-  __shared__ double sm[(NB / 16) * (NB / 16) * 256 + (NB / 16) * DT_STRIDE + (NTRI + NB / 16) / 2 + 2];
   potrf_flow<NB>(p.A + z * p.sA, p.lda, p.L + z * p.sL, p.ldl, p.W + z * p.sW, p.info + z * p.s_info, p.col0,
                  p.wait_flag ? p.wait_flag + z * p.s_flag : nullptr, p.wait_count,
                  p.done_flag ? p.done_flag + z * p.s_flag : nullptr, p.wait_ticks, sm);
-#else
-  __shared__ double sm[2 * NTRI * 256 + LEAF_SHARE_DOUBLES];
-  potrf_block<NB, NWAVES>(p.A + z * p.sA, p.lda, p.L + z * p.sL, p.ldl, p.W + z * p.sW, p.info + z * p.s_info, p.col0,
-                          p.wait_flag ? p.wait_flag + z * p.s_flag : nullptr, p.wait_count,
-                          p.done_flag ? p.done_flag + z * p.s_flag : nullptr, p.wait_ticks, sm);
-#endif
 }
 
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& q) {
@@ -1102,7 +638,7 @@ int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& q) {
       hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
       break;
     case 128:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<128, POTRF_WAVES_128>), grid, dim3(64 * POTRF_WAVES_128), 0, s, nullptr, q.stop_event, 0, p);
+      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

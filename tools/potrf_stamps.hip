@@ -32,7 +32,6 @@ static void run(int nwaves_label) {
   for (int rep = 0; rep < 3; ++rep) launch_potrf_diag(nullptr, 0, pl);
   hipDeviceSynchronize();
   unsigned long long st[512]; hipMemcpy(st, dst, sizeof(st), hipMemcpyDeviceToHost);
-#if GPX_POTRF_FLOW
   printf("NB=%d (dataflow): barrier after %llu cycles, first leaf starts after %llu\n", NB, st[1] - st[0], st[2] - st[0]);
   for (int jb = 0; jb < NT; ++jb)
     printf("  stage %d: leaf %llu cycles, hand-over to the next leaf %lld\n", jb, st[3 + 2 * jb] - st[2 + 2 * jb],
@@ -57,18 +56,6 @@ static void run(int nwaves_label) {
   printf("\n");
   printf("  whole kernel %llu cycles (%.1f us @2.4GHz); last wave done %llu\n", st[3 + 2 * NT] - st[0], (st[3 + 2 * NT] - st[0]) / 2400.0,
          st[2 + 2 * NT] - st[0]);
-#else
-  printf("NB=%d: load %llu cycles, first leaf %llu\n", NB, st[1] - st[0], st[2] - st[1]);
-  printf("  first leaf: wave0 (potrf) done after %llu cycles, wave1 (inverse) after %llu\n", st[40] - st[1], st[41] - st[1]);
-  unsigned long long pa = 0, sh = 0;
-  for (int jb = 0; jb < NT; ++jb) {
-    unsigned long long a_ = st[3 + 2 * jb] - st[2 + 2 * jb], b_ = st[2 + 2 * (jb + 1)] - st[3 + 2 * jb];
-    printf("  jb=%d phaseA %llu  shadow slot (leaf || update+inverse) %llu\n", jb, a_, b_);
-    pa += a_; sh += b_;
-  }
-  printf("  totals: phaseA %llu slots %llu store %llu ; whole kernel %llu cycles (%.1f us @2.4GHz)\n", pa, sh,
-         st[3 + 2 * NT] - st[2 + 2 * NT], st[3 + 2 * NT] - st[0], (st[3 + 2 * NT] - st[0]) / 2400.0);
-#endif
   // correctness spot check
   std::vector<double> l(NB * NB), w(NB * NB);
   hipMemcpy(l.data(), dL, NB * NB * 8, hipMemcpyDeviceToHost);
@@ -85,4 +72,91 @@ static void run(int nwaves_label) {
   printf("  max|LL^T-A| = %.2e  max|L W - I| = %.2e\n", e1, e2);
 }
 
-int main() { run<64>(4); run<128>(8); return 0; }
+
+// ---- probe: the cost of one streaming solve when every column is already published (one wave alone, or 8 waves at once)
+__global__ __launch_bounds__(512) void stream_probe(double* out, unsigned long long* clk, int mode) {
+  __shared__ double dt[DT_STRIDE];
+  __shared__ double tile[8][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fk = lane >> 4;
+  for (int t = tid; t < DT_STRIDE; t += blockDim.x) dt[t] = 0.0;
+  __syncthreads();
+  for (int t = tid; t < 256; t += blockDim.x) { const int c = t / 16, r = t % 16; dt[t] = (r == c) ? 2.0 : (r > c ? 0.01 * (r - c) : 0.0); }
+  if (tid < 16) dt[DT_RINV + tid] = 0.5;
+  for (int t = lane; t < 256; t += 64) tile[w][t] = 1.0 + 0.001 * t;
+  __syncthreads();
+  if (tid == 0) reinterpret_cast<int*>(dt + DT_EPOCH)[0] = 16;
+  __syncthreads();
+  int info = 0;
+  double* Xt = tile[w];
+  if (mode >= 2 && w != 0) {
+    // partner load: waves on wave 0's SIMD (w == 4) or elsewhere run back-to-back MFMAs (mode 2: independent, 3: dependent)
+    if ((mode & 4) ? (w == 1) : (w == 4)) {
+      v4d a0 = {0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+      double x = tile[w][lane];
+      const unsigned long long m0 = __builtin_amdgcn_s_memtime();
+      for (int it = 0; it < 600; ++it) {
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a0, 0, 0, 0);
+        if ((mode & 3) == 2) {
+          a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a1, 0, 0, 0);
+          a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+          a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a3, 0, 0, 0);
+        }
+      }
+      out[tid] = a0[0] + a1[0] + a2[0] + a3[0];
+      const unsigned long long m1 = __builtin_amdgcn_s_memtime();
+      if (lane == 0) clk[7] = (m1 - m0) / (((mode & 3) == 2) ? 2400 : 600);
+    }
+    return;
+  }
+  unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int rep = 0; rep < 16; ++rep) {
+    double u[1][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u[0][q] = Xt[eix(fk + 4 * q, fr)];
+    if (mode == 0) {
+      stream_solve<1, false>(dt, u, lane, &info, [&](auto S, double rk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Xt[eix(fk + 4 * q, fr)] = u[0][q] * rk;
+      });
+    } else {
+      v4d acc = {0.0, 0.0, 0.0, 0.0};
+      double xp = 0.0;
+      stream_solve<1, true>(dt, u, lane, &info, [&](auto S, double rk) {
+        constexpr int s = decltype(S)::value;
+        if constexpr (s > 0) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xp, xp, acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Xt[eix(fk + 4 * q, fr)] = u[0][q] * rk;
+        xp = Xt[eix(fr, 4 * s + fk)];
+      });
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xp, xp, acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) Xt[eix(fk + 4 * q, fr)] += 1e-30 * acc[q];
+    }
+  }
+  unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  if (lane == 0) clk[w] = (t1 - t0) / 16;
+  out[tid] = Xt[lane];
+}
+void run_probe() {
+  double* out; unsigned long long* clk;
+  hipMalloc(&out, 512 * 8); hipMalloc(&clk, 8 * 8);
+  for (int mode = 2; mode <= 7; ++mode) {
+    if ((mode & 3) < 2) continue;
+    hipLaunchKernelGGL(stream_probe, dim3(1), dim3(512), 0, 0, out, clk, mode);
+    hipLaunchKernelGGL(stream_probe, dim3(1), dim3(512), 0, 0, out, clk, mode);
+    hipDeviceSynchronize();
+    unsigned long long h[8]; hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+    printf("stream_solve probe (F1 form) with a wave of %s MFMAs on %s SIMD: %llu cycles per solve\n", (mode & 3) == 2 ? "independent" : "dependent",
+           (mode & 4) ? "another" : "the same", h[0]);
+    printf("    (that wave: %llu cycles per MFMA)\n", h[7]);
+  }
+  for (int nw = 1; nw <= 8; nw *= 2)
+    for (int mode = 0; mode < 2; ++mode) {
+      hipLaunchKernelGGL(stream_probe, dim3(1), dim3(64 * nw), 0, 0, out, clk, mode);
+      hipLaunchKernelGGL(stream_probe, dim3(1), dim3(64 * nw), 0, 0, out, clk, mode);
+      hipDeviceSynchronize();
+      unsigned long long h[8]; hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+      printf("stream_solve probe: %d wave(s), %s: %llu cycles per solve (wave 0)\n", nw, mode ? "F1 form (MFMA per group)" : "plain", h[0]);
+    }
+}
+int main() { run<64>(4); run<128>(8); run_probe(); return 0; }
