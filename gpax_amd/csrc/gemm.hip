@@ -205,16 +205,21 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   // operands of the last chunk, while the second-to-last chunk is still to be multiplied -- so that two chunks of
   // MFMAs cover it and no operand load queues behind it.  (The code is peeled so that this is straight-line: inside
   // a loop with a condition the compiler's wait-count pass falls back to vmcnt(0) before the last chunk's LDS store.)
+  // C addresses = a wave-uniform base (SGPR pair per tile row: the wave index goes through readfirstlane) + ONE 32-bit
+  // per-lane offset: sixteen 64-bit address pairs in VGPRs cost the kernel its last registers (it spilled two, and a
+  // spill's scratch traffic waits on vmcnt(0), i.e. for every operand load in flight)
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  double* const cw = g.C + (m0 + (wave_u >> 1) * (BM / 2)) * g.ldc + n0 + (wave_u & 1) * (BN / 2);
+  const unsigned c_lane = (unsigned)(fk * (int)g.ldc + fr);
   auto load_c = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const double* cp = g.C + (m0 + wm * (BM / 2) + i * 16 + fk) * g.ldc + n0 + wn * (BN / 2) + j * 16 + fr;
 #pragma unroll
         // (non-temporal C loads: 71 -> 61 us standalone on some boxes, but 1.765 -> 1.81 ms per N = 4096 step in situ --
         // the next kernels re-read these tiles from the caches -- so the default policy stays)
-        for (int r = 0; r < 4; ++r) cin[i][j][r] = cp[(int64_t)(4 * r) * g.ldc];
+        for (int r = 0; r < 4; ++r) cin[i][j][r] = (cw + (int64_t)(i * 16 + 4 * r) * g.ldc + j * 16)[c_lane];
       }
   };
   auto chunk = [&](int64_t k0, const bool prefetch, const bool request_c, const bool last) __attribute__((always_inline)) {
