@@ -25,6 +25,7 @@ ERR_NAMES = {
     -5: "GPX_ERR_COMM",
     -6: "GPX_ERR_UNSUPPORTED",
     -7: "GPX_ERR_RETRY",
+    -8: "GPX_ERR_INTERNAL",
 }
 ERR_RETRY = -7
 

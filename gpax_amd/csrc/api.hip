@@ -672,6 +672,11 @@ static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_ro
 // repeated -- by the synchronous entry points themselves (with_retry), by the caller of the asynchronous pair
 // (gpx_fetch_results returns GPX_ERR_RETRY; gpax_amd._lib.Core re-issues the step).
 static int check_handover(gpx_handle* h, int info) {
+  if (info == -8) {
+    h->have_factor = false; h->have_z = false;
+    gpx_set_error(h, "potrf_diag: a wait between its waves ran out (internal error); the results are undefined");
+    return GPX_ERR_INTERNAL;
+  }
   if (info != -7) return GPX_OK;
   h->resident = 0;
   h->have_factor = false; h->have_z = false;

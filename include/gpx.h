@@ -42,6 +42,8 @@ extern "C" {
 #define GPX_ERR_RETRY (-7)       /* an in-kernel hand-over timed out; the handle has switched to kernel-boundary hand-overs:
                                     repeat the call (the synchronous entry points do so themselves; of the asynchronous
                                     pair, gpx_fetch_results returns it) */
+#define GPX_ERR_INTERNAL (-8)    /* a bounded wait between the waves of potrf_diag ran out: a logic error, never observed;
+                                    the results of the call are undefined */
 
 typedef struct gpx_handle gpx_handle;
 
