@@ -204,9 +204,13 @@ __device__ __forceinline__ void flow_raise(int* flag, int value) {
   lds_order();
 }
 
-// wave w's leaf: L_jj.  As leaf_potrf, but the tile comes from / goes to the stage's diagonal area: rows are read from
-// the symmetric column-major tile, column j is published in place the moment it exists (l_ij by lane i, 1/l_jj, and
-// the epoch at the end of a reader group).
+// The 16 x 16 leaf: L_jj, one matrix row per lane (the 4 DPP rows of the wave work redundantly).  The rows are read from the
+// symmetric column-major tile of the stage's diagonal area; per column: 1/sqrt(pivot) by v_rsq_f64 + one cubic (Halley) step
+// (error O(e^3) ~ 1e-22, ~1 ulp after rounding; no denormal rescaling: pivots here are O(1e-6 .. 1e3)), the column scaled,
+// published in place the moment it exists (l_ij by lane i, 1/l_jj, the epoch at the end of a reader group), then the
+// rank-1 update of the columns to its right with the pivot row broadcast inside v_fmac_f64_dpp.  No predication at all:
+// finished rows (i <= j) only ever corrupt their own above-diagonal entries, which are don't-care.  LAPACK-style info: the
+// first non-positive (or NaN) pivot shows as the first diagonal entry that is not a positive number.
 __device__ __forceinline__ void flow_leaf(double* dt, int lane, int* info, int gcol0) {
   const int i = lane & 15;
   double a[16];

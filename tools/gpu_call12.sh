@@ -1,5 +1,3 @@
 #!/bin/bash
 set -e
-mkdir -p gpurun_out
-GPX_LIB_COMPAT=1 python3 tools/timeline2.py 4096 6 8 > gpurun_out/tl4096_mid.txt 2>&1
-cat gpurun_out/tl4096_mid.txt | head -80
+for n in 384 512 640 768; do python tools/opt_ab.py split_min_blocks 2,3,4,5,6,8 $n 300 | sort | awk '{print}' ; done
