@@ -440,7 +440,6 @@ __device__ __forceinline__ void potrf_flow(const double* A, int64_t lda, double*
 #pragma unroll
         for (int q = 0; q < 4; ++q) Xt[eix(fk + 4 * q, fr)] = u[0][q] * rk;
         xp = Xt[eix(fr, 4 * s + fk)];
-        GPX_STAMP_T(320 + w * 8 + s, 64 * w);
       });
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-xp, xp, acc, 0, 0, 0);
 #pragma unroll
