@@ -476,3 +476,23 @@ def test_device_acquisition_epilogue_matches_oracle_and_host_path():
     state.set_rng_key(21)
     x_host, val_host = host.optimize(gp, 1500)   # (re-draws the prior medians per batch, like the reference: compare loosely)
     assert x_host.shape == x_star.shape and np.isfinite(val_host)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bad", [1, 16, 17, 100, 128, 129, 144, 255, 256, 300, 511, 640, 700])
+def test_first_failing_pivot_is_reported_wherever_it_falls(core, bad):
+    """LAPACK-style info = the order of the first leading minor that is not positive definite, whichever wave of the
+    dataflow potrf_diag (one wave per 16 x 16 tile row, each running its own leaf) or whichever diagonal block meets it:
+    first / last column of a tile, of a 128-block, of the matrix (the reference returns NaNs silently)."""
+    import gpax_amd
+
+    n = 700
+    rng = np.random.default_rng(bad)
+    x = rng.uniform(-1, 1, (n, 2))
+    noise = np.full(n, 0.01)
+    noise[bad - 1] = -5.0   # diagonal entry 1 - 5 + jitter < 0
+    core.set_train(x)
+    prm = gpax_amd.make_params(0, 1.0, 1.0, None, noise, 1e-6)
+    info, _, l = core.fit_factor(prm, want_l=True)
+    assert info == bad
+    assert np.isfinite(l[: bad - 1, : bad - 1]).all()
