@@ -392,8 +392,10 @@ class Core:
         the last ``posterior`` / ``fit_predict`` left on the device.  Returns ``(values or None, argmax, best)``."""
         vals = np.empty(self.m) if want_values else None
         idx, best = C.c_int64(), C.c_double()
-        self._check(self._lib.gpx_acquisition(self._h, int(kind), float(param), float(mu_scale), float(mu_shift), float(sd_scale),
-                                              _ptr(vals), C.byref(idx), C.byref(best)), "gpx_acquisition")
+        info = self._check(self._lib.gpx_acquisition(self._h, int(kind), float(param), float(mu_scale), float(mu_shift), float(sd_scale),
+                                                     _ptr(vals), C.byref(idx), C.byref(best)), "gpx_acquisition")
+        if info > 0:   # the factor behind the resident (mean, var) was not positive definite: NaNs, as the reference's jax path gives
+            return (np.full(self.m, np.nan) if want_values else None), 0, float("nan")
         return vals, idx.value, best.value
 
     # -- batched hyper-parameter draws (gpax's vmap over hp samples, gpax/gp.py:354-364,384-390)

@@ -111,7 +111,7 @@ class AcquisitionFunction:
 
     def _device_path(self, model):
         return (self.DEVICE_KIND is not None and self.q == 1 and not self.force_monte_carlo and self.fast
-                and model.x is not None and model.y is not None)
+                and model.x is not None and model.y is not None and model._output_reverse_is_affine())
 
     def _device_values(self, model, x, want_values=True):
         return model._acquisition_fast(x, self.DEVICE_KIND, self._device_param(model), want_values)

@@ -186,15 +186,15 @@ static unsigned long long* g_tl_dev = nullptr;
 static unsigned long long* g_tl_ends = nullptr;
 extern "C" int gpx_timeline_start(void) {
   if (!g_tl_dev && hipMalloc(reinterpret_cast<void**>(&g_tl_dev), (4 + 4 * 16000) * 8) != hipSuccess) return -1;
-  if (!g_tl_ends && hipMalloc(reinterpret_cast<void**>(&g_tl_ends), 8192 * 8) != hipSuccess) return -1;
+  if (!g_tl_ends && hipMalloc(reinterpret_cast<void**>(&g_tl_ends), 16384 * 8) != hipSuccess) return -1;   // ends, then publish times
   (void)hipMemset(g_tl_dev, 0, (4 + 4 * 16000) * 8);
-  (void)hipMemset(g_tl_ends, 0, 8192 * 8);
+  (void)hipMemset(g_tl_ends, 0, 16384 * 8);
   tl_set_gemm(g_tl_dev, g_tl_ends); tl_set_potrf(g_tl_dev);
   return 0;
 }
 extern "C" long long gpx_timeline_read_ends(unsigned long long* out, long long max_records) {
   (void)hipDeviceSynchronize();
-  const long long n = max_records < 8192 ? max_records : 8192;
+  const long long n = max_records < 16384 ? max_records : 16384;
   (void)hipMemcpy(out, g_tl_ends, (size_t)n * 8, hipMemcpyDeviceToHost);
   return n;
 }
@@ -481,7 +481,7 @@ extern "C" int gpx_set_train(gpx_handle* h, const double* x, int64_t n, int32_t 
   if (h->d != d) { h->m = 0; }
   h->n = n; h->d = d;
   if (h->nb_auto) h->nb = n <= 64 ? 64 : 128;
-  h->have_factor = false; h->have_z = false; h->have_r = false;
+  h->have_factor = false; h->have_z = false; h->have_r = false; h->m_resident = 0;
   return GPX_OK;
 }
 
@@ -497,6 +497,7 @@ extern "C" int gpx_set_test(gpx_handle* h, const double* x_new, int64_t m) {
   }
   h->m = m;
   h->have_mnew = false;
+  h->m_resident = 0;   // whatever (mean, var) the result block holds belongs to the previous test inputs
   return GPX_OK;
 }
 
@@ -551,6 +552,7 @@ static int factor_prepare(gpx_handle* h, int64_t m_rows, bool with_r, int batch 
   GPX_RET(ensure_out(h, 2 * std::max<int64_t>(m_rows, 1), batch));
   GPX_RET(ensure_events(h, (size_t)(npad / nb), (int)nb, batch));
   h->have_factor = false; h->have_z = false;
+  h->m_resident = 0;   // the result block is about to be rewritten (gpx_posterior / gpx_fit_predict_async set it again)
   h->npad = npad; h->epad = epad; h->ld = ld;
   return GPX_OK;
 }
@@ -610,7 +612,7 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   }
   g.zero_info = h->d_info;
   if (h->d_flags) {   // the hand-over flags of the split-panel schedule are cleared by the same launch
-    g.zero_flags = h->d_flags; g.n_zero_flags = (int)(4 * (npad / h->nb));
+    g.zero_flags = h->d_flags; g.n_zero_flags = (int)(GPX_N_FLAG_ARRAYS * (npad / h->nb));
     h->flags_clean = true;
   }
   gram_cost(0, n, &fl, &by);
@@ -809,7 +811,7 @@ static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double
   const int64_t rows = npad + epad, n64 = round_up(n, 64);
   hipStream_t s = h->s_main;
 
-  h->have_factor = false; h->have_z = false;
+  h->have_factor = false; h->have_z = false; h->m_resident = 0;   // the result block is reused for alpha and the sums
   h->batch = 1; h->s_mat = rows * ld; h->s_w = npad * nb; h->s_z = npad; h->s_r = 0; h->s_mnew = 0;
   GPX_RET(ensure(h, &h->d_A, &h->a_cap, rows * ld));
   GPX_RET(ensure(h, &h->d_L, &h->l_cap, rows * ld));
@@ -1436,12 +1438,16 @@ extern "C" int gpx_acquisition(gpx_handle* h, int32_t kind, double param, double
   GPX_RET(ensure(h, &h->d_vec, &h->vec_cap, m + 2));
   GPX_RET(launch_acquisition(h, s, h->d_mean, h->d_mean + m, m, kind, param, mu_scale, mu_shift, sd_scale, h->d_vec, h->d_vec + m));
   std::vector<double> tail(2);
+  int info = 0;   // the factorisation's info word travels with the tail: after gpx_fit_predict_async without gpx_fetch_results
+                  // nobody has looked at it yet (non-PD factor: positive; a hand-over that timed out: GPX_ERR_RETRY)
   if (acq_out) GPX_HIP_CHECK(h, hipMemcpyAsync(acq_out, h->d_vec, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, s));
   GPX_HIP_CHECK(h, hipMemcpyAsync(tail.data(), h->d_vec + m, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(&info, h->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   GPX_HIP_CHECK(h, hipStreamSynchronize(s));
+  GPX_RET(check_handover(h, info));
   if (best_out) *best_out = tail[0];
   if (argmax_out) *argmax_out = (int64_t)tail[1];
-  return GPX_OK;
+  return info > 0 ? info : GPX_OK;
 }
 
 // ------------------------------------------------------------------------- runtime identity

@@ -42,6 +42,7 @@ struct GemmArgs {
   int64_t signal_m;   // > 0: only tiles with m0 < signal_m publish
   const unsigned* wait_flag; unsigned wait_count;   // one-pass path: resident start (see GemmLaunch::wait_flag)
   const unsigned* wait_flag2; unsigned wait_count2;
+  int64_t wait_m;     // > 0: only tiles with m0 < wait_m wait
   int* wait_info;     // set to -7 when the bounded wait gives up
   int tl_id;          // diagnostic timeline build only: launch number (index of this launch's end-time cell)
 };
@@ -86,9 +87,16 @@ void tl_set_gemm(unsigned long long* p, unsigned long long* ends) {
     if (threadIdx.x == 0 && g_tl_gemm_end && g.tl_id >= 0 && g.tl_id < 8192)                                 \
       atomicMax(&g_tl_gemm_end[g.tl_id], (unsigned long long)__builtin_amdgcn_s_memrealtime());              \
   } while (0)
+// [8192 + launch number] = latest time a workgroup of that launch raised its `signal` counter
+#define GEMM_TL_PUB()                                                                                        \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && g_tl_gemm_end && g.tl_id >= 0 && g.tl_id < 8192)                                 \
+      atomicMax(&g_tl_gemm_end[8192 + g.tl_id], (unsigned long long)__builtin_amdgcn_s_memrealtime());       \
+  } while (0)
 #else
 #define GEMM_TL(kind, a, b) do { } while (0)
 #define GEMM_TL_END() do { } while (0)
+#define GEMM_TL_PUB() do { } while (0)
 #endif
 
 // Diagnostic build only (tools/gemm_bench): s_memtime stamps of one workgroup's phases.
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  GEMM_TL(4, g.M, g.N * 1000000 + g.K);
+  GEMM_TL(ROLE == 1 ? 8 : 4, g.M, g.N * 1000000 + g.K);
   batch_offset(g);
   int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
   if (g.map_S < 0) {
@@ -282,6 +290,32 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   }
   GEMM_STAMP(13);
 
+  // The look-ahead instantiation (ROLE 1) can hand its first block row to an already-resident consumer -- the band kernel of
+  // the next step, asleep on `signal` -- the way the one-pass kernel does: write-through stores, each wave drains its own,
+  // the barrier collects the four waves, ONE lane adds to the agent-scope counter.  Same arithmetic, same bits; the bulk
+  // instantiation (ROLE 0) carries none of this.
+  if constexpr (ROLE == 1 && BM == 64) {
+    if (g.signal && m0 < g.signal_m) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int64_t col = n0 + wn * (BN / 2) + j * 16 + fr;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = m0 + wm * (BM / 2) + i * 16 + fk + 4 * r;
+            const double v = HASC ? fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]) : g.alpha * acc[i][j][r];
+            __hip_atomic_store(&g.C[row * g.ldc + col], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      GEMM_TL_PUB();
+      GEMM_TL_END();
+      return;
+    }
+  }
   // epilogue: lane (col = l&15, row group = l>>4), reg r -> row = (l>>4) + 4r
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -322,9 +356,45 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
 // independent one every ~100).  One global round trip and one barrier per tile instead of K/32.
 // (A register-only variant with per-lane contiguous K chunks was tried and measured slower:
 // its loads touch 64 different cache lines per instruction.)
-template <int K>
-__device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0, const int64_t n0, double* __restrict__ As,
-                                             double* __restrict__ Bs) {
+// One 32 x 32 tile, the pieces: a bounded resident wait, the tile product, the publication of its result.
+struct TileOp {
+  const double* A; const double* B; double* C;
+  int64_t lda, ldb, ldc;
+  double alpha, beta;
+  int b_lower_tri;
+};
+
+// resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
+__device__ __forceinline__ void onepass_wait(const unsigned* f1, unsigned c1, const unsigned* f2, unsigned c2, int* info) {
+  if (!f1 && !f2) return;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((f1 && __hip_atomic_load(f1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c1) ||
+           (f2 && __hip_atomic_load(f2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c2)) {
+      __builtin_amdgcn_s_sleep(4);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) { if (info) atomicMin(info, -7); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+}
+
+// after a published tile (write-through stores): each wave drains its own, the barrier collects the four waves, ONE lane
+// adds to the agent-scope counter the resident consumer polls
+__device__ __forceinline__ void onepass_signal(unsigned* counter) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// BIG: the summation order and the final rounding of gemm_nt_kernel<64,64,true> (ONE accumulator, fma(beta, C, alpha acc)),
+// so that a tile of a look-ahead column update gets the same bits whichever kernel computes it (the chain's band kernel
+// takes over one block of it, schedule.hip); otherwise two accumulators (a dependent f64 MFMA issues every ~190 cycles,
+// an independent one every ~100).  PUBLISH: write-through (sc1) stores for a consumer that is already resident.
+template <int K, bool BIG>
+__device__ __forceinline__ void onepass_tile(const TileOp& g, const int64_t m0, const int64_t n0, double* __restrict__ As,
+                                             double* __restrict__ Bs, const bool publish) {
   // LDS holds HALF of K at a time (K/2 + 4 doubles per row): 34 KB at K = 128, so four workgroups fit a CU and even the widest
   // panel of the factorisation is resident in a single round.  All global loads of BOTH halves are in
   // flight together; the second half waits in registers while the first is in the MFMAs.
@@ -333,21 +403,6 @@ __device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0
   constexpr int NCH = 32 * (KH / 2) / 256;   // 16-B chunks per thread, operand and half
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  if (g.wait_flag || g.wait_flag2) {   // resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
-    GEMM_TL(6, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));   // (timeline build) became resident
-    if (tid == 0) {
-      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-      while ((g.wait_flag && __hip_atomic_load(g.wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count) ||
-             (g.wait_flag2 && __hip_atomic_load(g.wait_flag2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < g.wait_count2)) {
-        __builtin_amdgcn_s_sleep(4);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 25000000ull) { if (g.wait_info) atomicMin(g.wait_info, -7); break; }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-  }
-  GEMM_TL(3, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));
   const double* Ag = g.A + m0 * g.lda;
   const double* Bg = g.B + n0 * g.ldb;
   // B lower triangular (the panel solve against W_k): B[n][k] = 0 for k > n, so the tile columns left of K/2 need
@@ -391,29 +446,40 @@ __device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0
       const v2d a = *reinterpret_cast<const v2d*>(Ap + 8 * s);
       const v2d b = *reinterpret_cast<const v2d*>(Bp + 8 * s);
       acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, b.x, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc1, 0, 0, 0);
+      if constexpr (BIG) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc0, 0, 0, 0);
+      else acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, b.y, acc1, 0, 0, 0);
     }
-  }
-  if (g.signal && (g.signal_m <= 0 || m0 < g.signal_m)) {
-    // publish: write-through (sc1) stores, each wave drains its own, the barrier collects the four waves, ONE
-    // lane adds to the agent-scope counter the resident consumer polls
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double v = g.alpha * (acc0[r] + acc1[r]);
-      if (g.beta != 0.0) v += g.beta * cin[r];
-      __hip_atomic_store(&cp[(int64_t)(4 * r) * g.ldc], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(g.signal, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    GEMM_TL_END();
-    return;
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    double v = g.alpha * (acc0[r] + acc1[r]);
-    if (g.beta != 0.0) v += g.beta * cin[r];
-    cp[(int64_t)(4 * r) * g.ldc] = v;
+    double v;
+    if constexpr (BIG) {
+      v = (g.beta != 0.0) ? fma(g.beta, cin[r], g.alpha * acc0[r]) : g.alpha * acc0[r];
+    } else {
+      v = g.alpha * (acc0[r] + acc1[r]);
+      if (g.beta != 0.0) v += g.beta * cin[r];
+    }
+    if (publish) __hip_atomic_store(&cp[(int64_t)(4 * r) * g.ldc], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else cp[(int64_t)(4 * r) * g.ldc] = v;
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void onepass_body(const GemmArgs& g, const int64_t m0, const int64_t n0, double* __restrict__ As,
+                                             double* __restrict__ Bs) {
+  if ((g.wait_flag || g.wait_flag2) && (g.wait_m <= 0 || m0 < g.wait_m)) {
+    GEMM_TL(6, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));   // (timeline build) became resident
+    onepass_wait(g.wait_flag, g.wait_count, g.wait_flag2, g.wait_count2, g.wait_info);
+  }
+  GEMM_TL(3, g.M, g.N * 1000000 + (g.beta != 0.0 ? 1 : 0));
+  TileOp t;
+  t.A = g.A; t.B = g.B; t.C = g.C; t.lda = g.lda; t.ldb = g.ldb; t.ldc = g.ldc; t.alpha = g.alpha; t.beta = g.beta;
+  t.b_lower_tri = g.b_lower_tri;
+  const bool publish = g.signal && (g.signal_m <= 0 || m0 < g.signal_m);
+  onepass_tile<K, false>(t, m0, n0, As, Bs, publish);
+  if (publish) {
+    onepass_signal(g.signal);
+    GEMM_TL_PUB();
   }
   GEMM_TL_END();
 }
@@ -428,28 +494,105 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   onepass_body<K>(g, m0, n0, As, Bs);
 }
 
-// The two band kernels of the chain in ONE launch (split-panel schedule with in-kernel hand-overs): every workgroup
-// first forms its 32x32 tile of S = A_{k+1,k} W_k^T (gs: sleeps on potrf_diag(k)'s flag, publishes the tile and counts
-// into gs.signal), then the workgroups of the lower tiles wait for all (nb/32)^2 tiles of S (gu.wait_flag = gs.signal)
-// and apply A_{k+1,k+1} -= S S^T to their tile (gu: publishes to the counter potrf_diag(k+1) polls).  The second kernel's
-// launch -- ~2 us between the two even back to back on one stream -- becomes a flag round trip inside a launch whose
-// 16 workgroups are all resident (they never wait for a workgroup that is not: phase 1 waits only for potrf_diag).
-// Phase 0 (gz.K > 0, lower tiles only): one more update of the SAME diagonal block, whose operands are ready before W_k
-// is -- the previous panel's contribution -- applied while the kernel would otherwise sleep.  The thread that stores an
-// entry in phase 0 is the thread that loads it in phase 2 (same tile, same lane map): program order, no fence.
+// ---- the chain's band kernel (split-panel schedule with in-kernel hand-overs) ---------------------------------------------
+// Between potrf_diag(k) and potrf_diag(k+1) the chain owns a window of TWO block rows below the diagonal block (k,k):
+//   row 1 (nb/32 x nb/32 workgroups, the critical ones):
+//     phase 0   A_{k+1,k+1} -= P P^T, P = L_{k+1,k-1}: the previous panel's contribution, applied while the kernel would
+//               otherwise sleep waiting for potrf_diag(k)  (lower tiles; the thread that stores an entry here is the thread
+//               that loads it in phase U: program order, no fence)
+//     phase S   S1 = A_{k+1,k} W_k^T       (sleeps on potrf_diag(k)'s flag; publishes its tile, counts into flagS)
+//     phase U   A_{k+1,k+1} -= S1 S1^T     (lower tiles; waits for all of S1; publishes to the counter potrf_diag(k+1) polls)
+//   row 2 (as many workgroups again, off the critical path: their deadline is the END of potrf_diag(k+1)):
+//     S2 = A_{k+2,k} W_k^T  (waits for W_k and for the panel stream's column updates of step k-1, flagF; into scratch: it is
+//               the next step's phase-0 operand P),  then  A_{k+2,k+1} -= S2 S1^T  -- the block that is the NEXT step's
+//               phase-S operand (published, counted into flagD: the panel stream's panel of step k+1 reads it too).
+// Round 2 had the panel stream update A_{k+2,k+1} and hand it to the band kernel of step k+1 through flagF: measured
+// (profiles/r03_critical_path_before.txt), that publication arrived within 0-6 us of potrf_diag(k+1)'s end in the chain-bound
+// middle of the factorisation and phase 0 + phase S then ran one after the other BEHIND it (gaps of 25-32 us between two
+// potrf_diag against 11 where it arrived early).  With row 2 the chain depends on the panel stream only two potrf_diag
+// later.  Same tile routines, same summation orders as before (row 2's update in the order of the kernel that used to do it:
+// `big`), so every output keeps its bits.
+struct BandArgs {
+  const double* W;                       // W_k (K x K, ld K)
+  const double* A1; const double* A2;    // A_{k+1,k}, A_{k+2,k} (ld)
+  double* D11; double* D21;              // A_{k+1,k+1}, A_{k+2,k+1} (ld)
+  const double* P0; int64_t ldp, sP0;    // phase-0 operand (nullptr: no phase 0), its leading dimension and per-draw stride
+  double* S1; double* S2;                // scratch K x K (ld K)
+  int64_t ld;
+  const unsigned* flagW; const unsigned* flagF; unsigned countF;
+  unsigned* flagS; unsigned* flagS2; unsigned* flagU; unsigned* flagD;
+  int* info;
+  int row2, big;
+  int64_t sA, sW, s_mini, s_flag, s_info;
+  int tl_id;
+};
+
+#ifdef GPX_TIMELINE
+#define BAND_TL(kind, beta)                                                                                  \
+  do {                                                                                                       \
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && g_tl_gemm) {            \
+      const unsigned long long slot = atomicAdd(g_tl_gemm, 1ull);                                            \
+      if (slot < 16000) {                                                                                    \
+        unsigned long long* r = g_tl_gemm + 4 + 4 * slot;                                                    \
+        r[0] = (unsigned long long)(kind) | ((unsigned long long)(b.tl_id + 1) << 8); r[1] = __builtin_amdgcn_s_memrealtime(); \
+        r[2] = (unsigned long long)K; r[3] = (unsigned long long)K * 1000000ull + (beta);                    \
+      }                                                                                                      \
+    }                                                                                                        \
+  } while (0)
+#else
+#define BAND_TL(kind, beta) do { } while (0)
+#endif
+
 template <int K>
-__global__ __launch_bounds__(256, 2) void chain_band_kernel(GemmArgs gz, GemmArgs gs, GemmArgs gu) {
+__global__ __launch_bounds__(256, 2) void chain_band_kernel(BandArgs b) {
   __shared__ __attribute__((aligned(16))) double As[32 * (K / 2 + 4)];
   __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
-  const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
-  batch_offset(gz); batch_offset(gs); batch_offset(gu);
-  if (gz.K > 0 && n0 <= m0) {
-    onepass_body<K>(gz, m0, n0, As, Bs);
-    __syncthreads();   // the LDS image is reused by phase 1
+  constexpr int NT = K / 32;
+  const int row = (int)blockIdx.y / NT;
+  const int64_t m0 = (int64_t)((int)blockIdx.y % NT) * 32, n0 = (int64_t)blockIdx.x * 32;
+  const int64_t z = blockIdx.z;
+  if (z) {
+    b.W += z * b.sW; b.A1 += z * b.sA; b.A2 += z * b.sA; b.D11 += z * b.sA; b.D21 += z * b.sA;
+    if (b.P0) b.P0 += z * b.sP0;
+    b.S1 += z * b.s_mini; b.S2 += z * b.s_mini;
+    b.flagW += z * b.s_flag; if (b.flagF) b.flagF += z * b.s_flag;
+    b.flagS += z * b.s_flag; b.flagS2 += z * b.s_flag; b.flagU += z * b.s_flag; b.flagD += z * b.s_flag;
+    b.info += z * b.s_info;
   }
-  onepass_body<K>(gs, m0, n0, As, Bs);
-  if (n0 > m0) return;   // strictly upper tile of the diagonal block
-  onepass_body<K>(gu, m0, n0, As, Bs);
+  TileOp t;
+  if (row == 0) {
+    if (b.P0 && n0 <= m0) {
+      BAND_TL(3, 1);
+      t.A = b.P0; t.B = b.P0; t.C = b.D11; t.lda = b.ldp; t.ldb = b.ldp; t.ldc = b.ld; t.alpha = -1.0; t.beta = 1.0; t.b_lower_tri = 0;
+      onepass_tile<K, false>(t, m0, n0, As, Bs, false);
+      __syncthreads();   // the LDS image is reused by phase S
+    }
+    BAND_TL(6, 0);
+    onepass_wait(b.flagW, 1u, nullptr, 0u, b.info);
+    BAND_TL(3, 0);
+    t.A = b.A1; t.B = b.W; t.C = b.S1; t.lda = b.ld; t.ldb = K; t.ldc = K; t.alpha = 1.0; t.beta = 0.0; t.b_lower_tri = 1;
+    onepass_tile<K, false>(t, m0, n0, As, Bs, true);
+    onepass_signal(b.flagS);
+    if (n0 > m0) return;   // strictly upper tile of the diagonal block
+    BAND_TL(6, 1);
+    onepass_wait(b.flagS, (unsigned)(NT * NT), nullptr, 0u, b.info);
+    BAND_TL(3, 1);
+    t.A = b.S1; t.B = b.S1; t.C = b.D11; t.lda = K; t.ldb = K; t.ldc = b.ld; t.alpha = -1.0; t.beta = 1.0; t.b_lower_tri = 0;
+    onepass_tile<K, false>(t, m0, n0, As, Bs, true);
+    onepass_signal(b.flagU);
+    return;
+  }
+  // row 2
+  onepass_wait(b.flagW, 1u, b.flagF, b.countF, b.info);
+  t.A = b.A2; t.B = b.W; t.C = b.S2; t.lda = b.ld; t.ldb = K; t.ldc = K; t.alpha = 1.0; t.beta = 0.0; t.b_lower_tri = 1;
+  onepass_tile<K, false>(t, m0, n0, As, Bs, true);
+  onepass_signal(b.flagS2);
+  onepass_wait(b.flagS, (unsigned)(NT * NT), b.flagS2, (unsigned)(NT * NT), b.info);
+  t.A = b.S2; t.B = b.S1; t.C = b.D21; t.lda = K; t.ldb = K; t.ldc = b.ld; t.alpha = -1.0; t.beta = 1.0; t.b_lower_tri = 0;
+  // published: the next reader outside this stream is the panel stream's panel of step k+1, whose first block row polls flagD
+  if (b.big) onepass_tile<K, true>(t, m0, n0, As, Bs, true);
+  else onepass_tile<K, false>(t, m0, n0, As, Bs, true);
+  onepass_signal(b.flagD);
 }
 
 static void fill_args(GemmArgs& g, const GemmLaunch& L) {
@@ -461,34 +604,31 @@ static void fill_args(GemmArgs& g, const GemmLaunch& L) {
   g.map_S = 0; g.map_ntj = 0;
   g.sA = L.sA; g.sB = L.sB; g.sC = L.sC; g.s_flag = L.s_flag; g.s_info = L.s_info;
   g.signal = L.signal; g.signal_m = L.signal_m; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
-  g.wait_flag2 = L.wait_flag2; g.wait_count2 = L.wait_count2;
+  g.wait_flag2 = L.wait_flag2; g.wait_count2 = L.wait_count2; g.wait_m = L.wait_m;
   g.tl_id = -1;
 }
 
-// S (nb x nb, L.N == L.M == L.K == nb) and the update of the diagonal block in one launch; both launches as the caller
-// would have issued them separately, S.signal / U.wait_flag pointing at the same zeroed counter
-int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch* Z, const GemmLaunch& S, const GemmLaunch& U) {
-  const int64_t nb = S.K;
-  if ((nb != 128 && nb != 64) || S.M != nb || S.N != nb || U.M != nb || U.N != nb || U.K != nb || !S.signal || U.wait_flag != S.signal ||
-      U.wait_count != (unsigned)((nb / 32) * (nb / 32))) {
+int launch_chain_band(gpx_handle* h, hipStream_t s, const BandLaunch& L) {
+  const int64_t nb = L.nb;
+  if ((nb != 128 && nb != 64) || !L.W || !L.A1 || !L.D11 || !L.S1 || !L.S2 || !L.flagW || !L.flagS || !L.flagS2 || !L.flagU || !L.flagD || !L.info ||
+      (L.row2 && (!L.A2 || !L.D21)) || (L.flagF && !L.row2) || L.batch < 1) {
     gpx_set_error(h, "chain_band: contract violated");
     return GPX_ERR_ARG;
   }
-  GemmArgs gz, gs, gu;
-  fill_args(gs, S); fill_args(gu, U);
-  if (Z) {
-    if (Z->M != nb || Z->N != nb || Z->K != nb || Z->C != U.C || Z->signal || Z->wait_flag) { gpx_set_error(h, "chain_band: phase-0 contract violated"); return GPX_ERR_ARG; }
-    fill_args(gz, *Z);
-  } else {
-    fill_args(gz, U); gz.K = 0; gz.signal = nullptr; gz.wait_flag = nullptr;
-  }
+  BandArgs b;
+  b.W = L.W; b.A1 = L.A1; b.A2 = L.row2 ? L.A2 : L.A1; b.D11 = L.D11; b.D21 = L.row2 ? L.D21 : L.D11;
+  b.P0 = L.P0; b.ldp = L.ldp; b.sP0 = L.sP0; b.S1 = L.S1; b.S2 = L.S2; b.ld = L.ld;
+  b.flagW = L.flagW; b.flagF = L.flagF; b.countF = L.countF; b.flagS = L.flagS; b.flagS2 = L.flagS2; b.flagU = L.flagU; b.flagD = L.flagD;
+  b.info = L.info; b.row2 = L.row2; b.big = L.big;
+  b.sA = L.sA; b.sW = L.sW; b.s_mini = L.s_mini; b.s_flag = L.s_flag; b.s_info = L.s_info;
 #ifdef GPX_TIMELINE
-  gs.tl_id = g_tl_launch++; gu.tl_id = g_tl_launch++;
+  b.tl_id = g_tl_launch++;
+#else
+  b.tl_id = -1;
 #endif
-  if (S.batch != U.batch || (Z && Z->batch != S.batch)) { gpx_set_error(h, "chain_band: batch mismatch"); return GPX_ERR_ARG; }
-  dim3 grid((unsigned)(nb / 32), (unsigned)(nb / 32), (unsigned)S.batch);
-  if (nb == 128) hipExtLaunchKernelGGL((chain_band_kernel<128>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gz, gs, gu);
-  else hipExtLaunchKernelGGL((chain_band_kernel<64>), grid, dim3(256), 0, s, nullptr, U.stop_event, 0, gz, gs, gu);
+  dim3 grid((unsigned)(nb / 32), (unsigned)((L.row2 ? 2 : 1) * (nb / 32)), (unsigned)L.batch);
+  if (nb == 128) hipExtLaunchKernelGGL((chain_band_kernel<128>), grid, dim3(256), 0, s, nullptr, L.stop_event, 0, b);
+  else hipExtLaunchKernelGGL((chain_band_kernel<64>), grid, dim3(256), 0, s, nullptr, L.stop_event, 0, b);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
@@ -508,8 +648,11 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
 #else
   g.tl_id = -1;
 #endif
-  if ((L.signal || L.wait_flag) && !(L.small_tile && (L.K == 128 || L.K == 64))) {
-    gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel only");
+  // hand-overs inside a launch: the one-pass kernel (publish and wait), or the 64x64 look-ahead instantiation (publish its
+  // first `signal_m` rows only)
+  const bool big_signal = !L.small_tile && L.role == 1 && L.beta != 0.0 && L.signal && L.signal_m > 0 && L.signal_m % 64 == 0 && !L.wait_flag;
+  if ((L.signal || L.wait_flag) && !(L.small_tile && (L.K == 128 || L.K == 64)) && !big_signal) {
+    gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel and the 64x64 look-ahead kernel only");
     return GPX_ERR_ARG;
   }
   if (L.a_upper_tri && L.small_tile) {

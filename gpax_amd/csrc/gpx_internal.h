@@ -97,7 +97,8 @@ struct GemmLaunch {
   // one-pass path: the kernel is launched early and sleeps until *wait_flag >= wait_count (a producer that is
   // still running publishes its output with write-through stores and then raises the flag)
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;
-  const unsigned* wait_flag2 = nullptr; unsigned wait_count2 = 0;   // a second producer (band kernel: the panel stream's column update)
+  const unsigned* wait_flag2 = nullptr; unsigned wait_count2 = 0;   // a second producer
+  int64_t wait_m = 0;     // > 0: only the tiles whose first row is below wait_m wait (the rest start at once)
   int* wait_info = nullptr;   // device int set to -7 if the bounded wait gives up
   // batched hyper-parameter draws (blockIdx.z = draw): per-draw strides in elements (doubles for A/B/C, unsigned for the
   // flags, int for wait_info); 0 = shared by the draws
@@ -105,8 +106,30 @@ struct GemmLaunch {
   int64_t sA = 0, sB = 0, sC = 0, s_flag = 0, s_info = 0;
 };
 int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& g);
-// the chain's two band kernels in one launch; Z (optional): an update of the same diagonal block applied first, before the wait for W_k
-int launch_chain_band(gpx_handle* h, hipStream_t s, const GemmLaunch* Z, const GemmLaunch& S, const GemmLaunch& U);
+// the chain's band kernel (gemm.hip, chain_band_kernel): the diagonal band between potrf_diag(k) and potrf_diag(k+1) in one
+// launch -- phase 0 (optional), S1 = A_{k+1,k} W_k^T, A_{k+1,k+1} -= S1 S1^T, and (row2) S2 = A_{k+2,k} W_k^T,
+// A_{k+2,k+1} -= S2 S1^T
+struct BandLaunch {
+  int nb = 128;
+  const double* W = nullptr;
+  const double* A1 = nullptr; const double* A2 = nullptr;
+  double* D11 = nullptr; double* D21 = nullptr;
+  const double* P0 = nullptr; int64_t ldp = 0, sP0 = 0;   // phase-0 operand L_{k+1,k-1}
+  double* S1 = nullptr; double* S2 = nullptr;             // scratch nb x nb each
+  int64_t ld = 0;
+  const unsigned* flagW = nullptr;                          // raised by potrf_diag(k) behind W_k
+  const unsigned* flagF = nullptr; unsigned countF = 0;     // row 2: tiles published by the panel stream's column updates of step k-1
+  unsigned* flagS = nullptr; unsigned* flagS2 = nullptr;    // tiles of S1 / S2 published
+  unsigned* flagU = nullptr;                                // tiles of A_{k+1,k+1} published (potrf_diag(k+1) polls)
+  unsigned* flagD = nullptr;                                // tiles of A_{k+2,k+1} published (the panel stream's panel of step k+1 polls)
+  int* info = nullptr;
+  int row2 = 0, big = 0;   // big: row 2's update in the summation order of the 64x64 look-ahead kernel
+  hipEvent_t stop_event = nullptr;
+  int batch = 1;
+  int64_t sA = 0, sW = 0, s_mini = 0, s_flag = 0, s_info = 0;
+};
+int launch_chain_band(gpx_handle* h, hipStream_t s, const BandLaunch& L);
+#define GPX_N_FLAG_ARRAYS 6   // flagsU, flagsW, flagsS, flagsF, flagsS2, flagsD: nblk words each, per draw
 
 // Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
 struct PotrfLaunch {
@@ -225,13 +248,14 @@ struct gpx_handle {
   // P (s_main): the chain -- diagonal blocks; P2 (s_main2): the chain's band kernels; Q (s_far): panels and look-ahead
   // columns; T (s_trail): bulk updates
   hipStream_t s_main = nullptr, s_trail = nullptr, s_far = nullptr, s_main2 = nullptr;
-  unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per draw: flagsU, flagsW, flagsS, flagsF (nblk each)
+  unsigned* d_flags = nullptr; int64_t flags_cap = 0;   // per draw: flagsU, flagsW, flagsS, flagsF, flagsS2, flagsD (nblk each)
   bool flags_clean = false;        // the flags were cleared by the gram launch of this call (no memset needed)
   hipEvent_t ev_chain2 = nullptr;
   const EpilogueLaunch* epi = nullptr;   // set by fit_predict around the factorisation: the split-panel loop may launch the early half
   int64_t epi_split_col = 0;             // columns [0, epi_split_col) were reduced early into d_epart (0: not split)
   double* d_epart = nullptr; int64_t epart_cap = 0;
   hipEvent_t ev_build = nullptr;   // K built on the chain stream -> the border rows are built on the panel stream
+  hipEvent_t ev_near = nullptr;    // the panel stream's most recent near-block launch (split-panel schedule, grouped phases)
   std::string err;
   hipDeviceProp_t prop;
 
@@ -311,7 +335,7 @@ struct gpx_handle {
   std::vector<hipEvent_t> ev_panel, ev_trail;
   hipEvent_t ev_join = nullptr, ev_join2 = nullptr;
   std::vector<hipEvent_t> ev_far, ev_w;
-  double* d_mini = nullptr; int64_t mini_cap = 0;   // per draw: 2 x (nb x nb) scratch of the split-panel schedule (L_{k+1,k} for the chain)
+  double* d_mini = nullptr; int64_t mini_cap = 0;   // per draw: 4 x (nb x nb) scratch of the split-panel schedule (S1 = L_{k+1,k} and S2 = L_{k+2,k} of the chain, alternating)
 
   DistState dist;
 

@@ -108,6 +108,7 @@ __device__ __forceinline__ void fnmac_bcast(double& acc, double src, double mul)
 // for a diagonal tile of L the don't-care entries above the diagonal become zeros
 // W_k is published with plain stores and ONE agent-scope release per wave in front of the flag (write-through stores
 // of every W tile lengthened the kernel by a quarter).
+template <bool WT>
 __device__ __forceinline__ void store_tile(const double* tiles, double* dst, int64_t ld, int ib, int jb, int lane,
                                            bool zero_upper_of_diag) {
   const int r = lane >> 2, c4 = (lane & 3) * 4;
@@ -120,7 +121,10 @@ __device__ __forceinline__ void store_tile(const double* tiles, double* dst, int
     if (zero_upper_of_diag && ib == jb && c4 + q > r) v[q] = 0.0;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) out[q] = v[q];
+  for (int q = 0; q < 4; ++q) {
+    if constexpr (WT) __hip_atomic_store(&out[q], v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else out[q] = v[q];
+  }
 }
 
 #ifdef GPX_TIMELINE
@@ -247,7 +251,8 @@ __device__ __forceinline__ void flow_leaf(double* dt, int lane, int* info, int g
     });
   });
   const unsigned long long bad = __ballot(!(a[i] > 0.0)) & 0xffffull;
-  if (bad && lane == 0 && *info == 0) *info = gcol0 + __ffsll((long long)bad);
+  // first failing pivot wins, and a negative code (-7 / -8, raised with atomicMin by another wave) is never overwritten
+  if (bad && lane == 0) atomicCAS(info, 0, gcol0 + (int)__ffsll((long long)bad));
 }
 
 // Forward substitution  L_jj y = rhs  behind the leaf that is producing L_jj, NR right-hand sides at once.
@@ -355,7 +360,12 @@ __device__ __forceinline__ void flow_store_lower(const double* Lt, double* dst, 
   for (int q = 0; q < 4; ++q) out[q] = src[eix(r, c4 + q)];
 }
 
-template <int NB>
+// WT: W_k is published to an already-resident consumer (done_flag): its stores are write-through (agent scope), so that
+// the flag can go up behind a plain `s_waitcnt vmcnt(0)`.  Round 2 used plain stores and ONE agent-scope release for the
+// block; measured in situ (profiles/r03_critical_path_*.txt) that release -- a write-back of the XCD's whole L2 -- takes
+// ~10 us while a bulk update is filling that L2 with dirty C tiles, i.e. in every step of the first two thirds of a
+// factorisation (the band kernel started 12-14 us after potrf_diag's last instruction there, 2-3 us in the last steps).
+template <int NB, bool WT>
 __device__ __forceinline__ void potrf_flow(const double* A, int64_t lda, double* __restrict__ L, int64_t ldl,
                                            double* __restrict__ W, int* info, int col0, const unsigned* wait_flag,
                                            unsigned wait_count, unsigned* done_flag, unsigned long long wait_ticks, double* sm) {
@@ -503,7 +513,7 @@ __device__ __forceinline__ void potrf_flow(const double* A, int64_t lda, double*
           for (int q = 0; q < 4; ++q) Wd[eix(fr, fk + 4 * q)] = u[0][q] * rk;
         });
         flow_raise(&winv[0], 1);
-        store_tile(Wt, W, NB, 0, 0, lane, false);
+        store_tile<WT>(Wt, W, NB, 0, 0, lane, false);
       } else {
         flow_wait(&winv[jb], 1, info);
       }
@@ -551,7 +561,11 @@ __device__ __forceinline__ void potrf_flow(const double* A, int64_t lda, double*
       double* ldst = L + (int64_t)(w * 16 + r4) * ldl + jb * 16 + c4;
       double* wdst = W + (int64_t)(w * 16 + r4) * NB + jb * 16 + c4;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { ldst[q] = 0.0; wdst[q] = 0.0; }
+      for (int q = 0; q < 4; ++q) {
+        ldst[q] = 0.0;
+        if constexpr (WT) __hip_atomic_store(&wdst[q], 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else wdst[q] = 0.0;
+      }
     }
   }
 
@@ -596,22 +610,23 @@ __device__ __forceinline__ void potrf_flow(const double* A, int64_t lda, double*
     p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Wd[eix(fr, 12 + fk)], Tp[eix(12 + fk, fr)], p1, 0, 0, 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q) Tp[eix(fk + 4 * q, fr)] = p0[q] + p1[q];
-    store_tile(Wt, W, NB, jb, w, lane, false);
-    if (w == jb - 1) store_tile(Wt, W, NB, jb, jb, lane, false);
+    store_tile<WT>(Wt, W, NB, jb, w, lane, false);
+    if (w == jb - 1) store_tile<WT>(Wt, W, NB, jb, jb, lane, false);
   }
 
   GPX_STAMP_T(2 + 2 * NT, 64 * (NT - 1));
   POTRF_TL(2, col0);
-  // publish W_k / L_kk to an already-resident consumer: every wave drains its plain stores, the barrier collects the waves,
-  // one lane releases (eight concurrent L2 write-backs, one per wave, cost the hand-over ~0.5 us: N=2048 0.598 -> 0.572 ms
-  // per step on the same box) and raises the flag
+  // publish W_k to an already-resident consumer (the band kernel, which reads W_k and nothing else of this block: L_kk
+  // reaches its readers through this kernel's completion event): every wave drains its write-through stores, the barrier
+  // collects the waves, one lane raises the flag
   if (done_flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have reached the L2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // ONE write-back of the XCD's dirty lines for the whole block
+      if constexpr (!WT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
       __hip_atomic_store(done_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    POTRF_TL(7, col0);
   }
   GPX_STAMP_T(3 + 2 * NT, 64 * (NT - 1));
 }
@@ -622,13 +637,13 @@ struct PotrfArgs {
   int64_t sA, sL, sW, s_info, s_flag;   // per-draw strides of a batched launch (blockIdx.x = draw)
 };
 
-template <int NB, int NWAVES>
+template <int NB, int NWAVES, bool WT>
 __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(PotrfArgs p) {
   constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
   static_assert(NWAVES == NT, "potrf_diag: one wave per block row");
   __shared__ double sm[NT * NT * 256 + NT * DT_STRIDE + (NTRI + NT) / 2 + 2];
   const int64_t z = blockIdx.x;
-  potrf_flow<NB>(p.A + z * p.sA, p.lda, p.L + z * p.sL, p.ldl, p.W + z * p.sW, p.info + z * p.s_info, p.col0,
+  potrf_flow<NB, WT>(p.A + z * p.sA, p.lda, p.L + z * p.sL, p.ldl, p.W + z * p.sW, p.info + z * p.s_info, p.col0,
                  p.wait_flag ? p.wait_flag + z * p.s_flag : nullptr, p.wait_count,
                  p.done_flag ? p.done_flag + z * p.s_flag : nullptr, p.wait_ticks, sm);
 }
@@ -642,10 +657,12 @@ int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& q) {
   const dim3 grid((unsigned)q.batch);
   switch (q.nb) {
     case 64:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
+      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, true>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
+      else hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, false>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
       break;
     case 128:
-      hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
+      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, true>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
+      else hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, false>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

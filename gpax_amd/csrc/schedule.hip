@@ -27,8 +27,9 @@ int ensure_events(gpx_handle* h, size_t nblk, int nb, int batch) {
   if (!h->ev_join2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_join2, fl));
   if (!h->ev_chain2) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_chain2, fl));
   if (!h->ev_build) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_build, fl));
-  h->s_flags = 4 * (int64_t)std::max<size_t>(nblk, 64);     // flagsU, flagsW, flagsS, flagsF
-  h->s_mini = 2 * (int64_t)nb * nb;
+  if (!h->ev_near) GPX_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_near, fl));
+  h->s_flags = GPX_N_FLAG_ARRAYS * (int64_t)std::max<size_t>(nblk, 64);     // flagsU, flagsW, flagsS, flagsF, flagsS2, flagsD
+  h->s_mini = 4 * (int64_t)nb * nb;                                         // S1 (two, alternating), S2 (two, alternating)
   GPX_RET(ensure(h, &h->d_flags, &h->flags_cap, h->s_flags * batch));
   GPX_RET(ensure(h, &h->d_mini, &h->mini_cap, h->s_mini * batch));
   while (h->ev_far.size() < nblk) {
@@ -190,7 +191,7 @@ struct SplitSchedule {
   hipStream_t P, P2, Q, T;
   bool resident, chain2, fuse_band, kinv, attach, use_dib, lp_flag = false;
   unsigned n_signal;
-  unsigned *flagsU, *flagsW, *flagsS, *flagsF;
+  unsigned *flagsU, *flagsW, *flagsS, *flagsF, *flagsS2, *flagsD;
   // "diagonal block in the band kernel" (fused band kernel, ungrouped steps).  The column update of step j used to
   // cover column j+2 from its diagonal block down, behind the wait for the bulk launch that last wrote that column, and
   // the band kernel of step j+1 waited for all of it -- on alternate block columns of the chain-bound middle of the
@@ -215,6 +216,7 @@ struct SplitSchedule {
   int64_t kinv_last = -1;     // last panel folded into K^-1 (gradient path)
   bool far_attached = false;  // per step: ev_far[k] rides on a kernel's own dispatch packet
   int64_t force_timeout_at = -1;   // test hook ("debug_force_timeout"): this step's potrf_diag waits for an impossible count
+  int64_t near_step = -1;     // step of a near-block launch on Q the chain has not been ordered behind yet (h->ev_near)
 
   int64_t group_size(int64_t left) const {
     return (quad_min > 0 && left > quad_min) ? 4 : ((pair_min > 0 && left > pair_min) ? 2 : 1);
@@ -247,7 +249,9 @@ struct SplitSchedule {
     flagsU = h->d_flags;              // [k]: tiles of A_{k+1,k+1} -= S S^T published (potrf_diag(k+1) waits)
     flagsW = h->d_flags + nblk;       // [k]: W_k published (S = A W_k^T of step k waits)
     flagsS = h->d_flags + 2 * nblk;   // [k]: tiles of S published (fused band kernel: its second phase waits)
-    flagsF = h->d_flags + 3 * nblk;   // [k]: block row k+2 of column k+1 brought up to date by the panel stream at step k (band kernel of step k+1 waits)
+    flagsF = h->d_flags + 3 * nblk;   // [k]: first block rows of the panel stream's column updates of step k published (row 2 of the band kernel of step k+1 waits)
+    flagsS2 = h->d_flags + 4 * nblk;  // [k]: tiles of S2 published (row 2 of the fused band kernel)
+    flagsD = h->d_flags + 5 * nblk;   // [k]: tiles of A_{k+2,k+1} published by row 2 (the first block row of Q's panel k+1 waits)
     // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
     // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
     pair_min = kinv ? std::min<int64_t>(h->pair_min, 8) : h->pair_min; quad_min = h->quad_min;
@@ -265,7 +269,7 @@ struct SplitSchedule {
     tev.assign((size_t)nblk, nullptr); t_pending.assign((size_t)nblk, 0);
     if (resident && h->debug_force_timeout) { force_timeout_at = 1; h->debug_force_timeout = 0; }
     if (resident && !h->flags_clean) {
-      if (M.batch == 1) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(4 * nblk) * sizeof(unsigned), P));
+      if (M.batch == 1) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(GPX_N_FLAG_ARRAYS * nblk) * sizeof(unsigned), P));
       else GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(h->s_flags * M.batch) * sizeof(unsigned), P));
     }
     h->flags_clean = false;
@@ -300,13 +304,15 @@ struct SplitSchedule {
       if (use_dib && mr > 0 && ncb > 1 && j - lt == 1) {
         dib[(size_t)(j + 1)] = 1;
         band_t[(size_t)(j + 1)] = (ti >= 0 && j + 2 >= tf) ? ti : -1;
-        // The band kernel of step j+1 learns of this step's column update (column j+1, whose first block row is its
-        // operand) through a device counter instead of a stream-level event wait in front of its launch -- it is then
-        // resident, asleep, when potrf_diag(j+1) ends -- wherever that update runs on the one-pass kernel, i.e. in the
-        // chain-bound steps.  With potrf_diag at 22 us the loop  potrf_diag(j) -> event -> panel -> column update -> event ->
-        // band launch  had become longer than  potrf_diag(j+1) + band: every other gap between two potrf_diag was 20 us
-        // instead of 10.
-        if (fuse_band && j + 2 < nblk && (h->la_rows <= 0 || mr < h->la_rows) && (nb == 128 || nb == 64)) far_flag[(size_t)j] = 1;
+        // far_flag[j] ("row 2", round 3): the band kernel of step j owns a window of TWO block rows -- it also forms
+        // S2 = A_{j+2,j} W_j^T and applies A_{j+2,j+1} -= S2 S1^T, the block that is the NEXT band kernel's operand, and its S2 is
+        // the next band kernel's phase-0 operand -- so that step j+1's critical phases need nothing from the panel stream.  The
+        // panel stream's column updates of step j then start one block lower (block row j+3) and publish their first block rows
+        // (flagsF[j], both the one-pass and the 64x64 look-ahead kernel can): row 2 of step j+1 waits for them inside the kernel,
+        // with a whole potrf_diag of slack.  (Round 2 handed A_{j+2,j+1} itself over through flagsF, and only where the update
+        // ran on the one-pass kernel; measured, that publication arrived within 0-6 us of potrf_diag(j+1)'s end in the middle of
+        // the factorisation, and phase 0 + S then ran behind it: gaps of 25-32 us between two potrf_diag against 11.)
+        if (fuse_band && j + 2 < nblk && (nb == 128 || nb == 64)) far_flag[(size_t)j] = 1;
       }
       if (j == ge) {
         if (nblk - (j + 3 + near) > 0) { ti = j; tf = j + 3 + near; }
@@ -362,8 +368,38 @@ struct SplitSchedule {
     if (k + 1 >= nblk) return GPX_OK;
     const bool far_by_flag = k >= 1 && far_flag[(size_t)(k - 1)] != 0;
     if (k >= 1 && !far_by_flag) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_far[(size_t)(k - 1)], 0));   // columns k, k+1 were brought up to date by Q at step k-1
+    // The near block of group end j (columns j+3 .. j+2+near, diagonal blocks included) is written by Q behind ev_far[j].
+    // The first band kernel that touches one of those columns is the one of step j+2; where it has no stream-level wait
+    // for Q (far_by_flag: its critical phases need nothing else from Q since round 3 -- round 2's in-kernel wait for Q's
+    // step-(k-1) updates ordered it implicitly) it waits for the near block's own event.
+    if (near_step >= 0 && k >= near_step + 2) {
+      if (far_by_flag) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_near, 0));
+      near_step = -1;   // (otherwise ev_far[k-1], k-1 > near_step, was recorded behind it)
+    }
+    const bool phase0 = dib[(size_t)k] != 0;   // block (k+1,k+1) -= L_{k+1,k-1} L_{k+1,k-1}^T (panel k-1), see dib[] above
+    if (phase0 && band_t[(size_t)k] >= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)band_t[(size_t)k]], 0));   // the bulk launch that last wrote the block
+    if (fuse_band) {   // the whole band (phase 0, S1, the diagonal block, and row 2) in one launch
+      BandLaunch b;
+      b.nb = (int)nb; b.W = c.W(k); b.ld = c.ld;
+      b.A1 = c.A(r0, c0); b.D11 = c.A(r0, r0);
+      b.row2 = far_flag[(size_t)k] != 0;
+      if (b.row2) { b.A2 = c.A(r0 + nb, c0); b.D21 = c.A(r0 + nb, r0); b.big = col_small(k) ? 0 : 1; }
+      b.S1 = S; b.S2 = h->d_mini + (2 + (k & 1)) * nb * nb;
+      if (phase0) {
+        // its operand L_{k+1,k-1}: the S2 the previous band kernel left in scratch (same stream: ordered), or -- where that
+        // kernel had no row 2 -- the official copy of the panel stream (ordered by the event wait above)
+        if (far_by_flag) { b.P0 = h->d_mini + (2 + ((k - 1) & 1)) * nb * nb; b.ldp = nb; b.sP0 = h->s_mini; }
+        else { b.P0 = c.L(r0, (k - 1) * nb); b.ldp = c.ld; b.sP0 = c.M.sA; }
+      }
+      b.flagW = flagsW + k; b.flagS = flagsS + k; b.flagS2 = flagsS2 + k; b.flagU = flagsU + k; b.flagD = flagsD + k; b.info = h->d_info;
+      if (b.row2 && far_by_flag) { b.flagF = flagsF + (k - 1); b.countF = far_count(k - 1); }
+      b.batch = c.M.batch; b.sA = c.M.sA; b.sW = c.M.sW; b.s_mini = h->s_mini; b.s_flag = h->s_flags; b.s_info = c.s_info;
+      prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * ((phase0 ? 3.0 : 2.0) + (b.row2 ? 2.0 : 0.0)) * (double)nb * nb * nb, B * 8.0 * 6.0 * nb * nb);
+      GPX_RET(launch_chain_band(h, PB, b));
+      prof_end(h, PB);
+      return GPX_OK;
+    }
     GemmLaunch g = c.panel(k, r0, nb, S, nb, h->s_mini);                                    // S = A_{k+1,k} W_k^T
-    if (chain2) { g.wait_flag = flagsW + k; g.wait_count = 1; g.wait_info = h->d_info; }   // W_k arrives in-kernel from potrf_diag(k)
     GemmLaunch u;                                                                           // A_{k+1,k+1} -= S S^T
     u.A = S; u.lda = nb; u.B = S; u.ldb = nb;
     u.C = c.A(r0, r0); u.ldc = c.ld;
@@ -371,24 +407,10 @@ struct SplitSchedule {
     u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 1;
     u.batch = c.M.batch; u.sA = h->s_mini; u.sB = h->s_mini; u.sC = c.M.sA; u.s_flag = h->s_flags; u.s_info = c.s_info;
     if (resident) u.signal = flagsU + k;   // potrf_diag(k+1) is already resident and polls this counter
-    GemmLaunch z;   // phase 0: block (k+1,k+1) -= L_{k+1,k-1} L_{k+1,k-1}^T (panel k-1), see dib[] above
-    const bool phase0 = dib[(size_t)k] != 0;
+    GemmLaunch z;
     if (phase0) {
-      if (band_t[(size_t)k] >= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)band_t[(size_t)k]], 0));   // the bulk launch that last wrote the block
       z = c.update(r0, nb, k + 1, 1, k - 1, 1, true);
       z.row_off = 0; z.col_off = 0;
-    }
-    if (fuse_band) {   // both band kernels (and phase 0) in one launch: S's tiles are handed over through flagsS[k]
-      if (far_by_flag) {
-        g.wait_flag2 = flagsF + (k - 1); g.wait_count2 = (unsigned)((nb / 32) * (nb / 32));
-        if (phase0) { z.wait_flag2 = g.wait_flag2; z.wait_count2 = g.wait_count2; z.wait_info = h->d_info; }
-      }
-      g.signal = flagsS + k;
-      u.wait_flag = flagsS + k; u.wait_count = (unsigned)((nb / 32) * (nb / 32)); u.wait_info = h->d_info;
-      prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * (phase0 ? 3.0 : 2.0) * (double)nb * nb * nb, B * 8.0 * 6.0 * nb * nb);
-      GPX_RET(launch_chain_band(h, PB, phase0 ? &z : nullptr, g, u));
-      prof_end(h, PB);
-      return GPX_OK;
     }
     if (phase0) {
       prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * (double)nb * nb * nb, B * 8.0 * 3.0 * nb * nb);
@@ -423,6 +445,11 @@ struct SplitSchedule {
     // cross-stream event -- crowds the bulk update with sleeping workgroups: 1.76 -> 1.81 ms, not used.)
     GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
     GemmLaunch g = c.panel(k, r0, mrows, c.L(r0, c0), c.ld, c.M.sA);
+    if (k >= 1 && far_flag[(size_t)(k - 1)]) {
+      // its first block row, A_{k+1,k}, was last written by row 2 of the band kernel of step k-1 (another stream): those
+      // tiles are published and counted; this panel starts behind potrf_diag(k), so the count is there and one poll passes
+      g.wait_flag = flagsD + (k - 1); g.wait_count = (unsigned)((nb / 32) * (nb / 32)); g.wait_m = nb; g.wait_info = h->d_info;
+    }
     // T gets its own event on the panel: the bulk update must not wait for the column kernels below (with one
     // shared event after them the N = 4096 step went from 1.90 to 2.17 ms: every bulk update starts late)
     const bool t_needs = (k + 1 < nblk && k == group_end && nblk - (k + 3 + near_cols) > 0) || (kinv && (k == group_end || k + 1 >= nblk));
@@ -461,15 +488,24 @@ struct SplitSchedule {
     return rc;
   }
 
+  // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
+  // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency.  The choice follows the
+  // STEP (rows below block row k+2), not the launch: a column whose update starts one block lower in one hand-over
+  // mode ("diagonal block in the band kernel") must get the same tile routine -- the same bits -- in every mode.
+  bool col_small(int64_t k) const { return !(h->la_rows > 0 && c.rows_at(k) - (k + 2) * nb >= h->la_rows); }
+  // what the two column updates of step k (far_flag[k]: both start at block row k+3) add to flagsF[k]: the tiles of
+  // their first block row, 32x32 or 64x64 ones
+  unsigned far_count(int64_t k) const {
+    const int64_t mr = c.rows_at(k) - (k + 3) * nb, tw = col_small(k) ? 32 : 64;
+    if (mr <= 0) return 0u;
+    return (unsigned)(2 * ((std::min<int64_t>(nb, mr) + tw - 1) / tw) * (nb / tw));
+  }
+
   // Q: columns [cfirst, cfirst+ncol) blocks, rows from block row k+2 (+ skip_blocks) down, -= panels [kfirst, kfirst+npan)
   int col_update(int64_t k, int64_t cfirst, int64_t ncol, int64_t kfirst, int64_t npan, bool last, int64_t skip_blocks = 0, bool raise_far = false) {
     const int64_t rows = c.rows_at(k), rr = (k + 2 + skip_blocks) * nb, mr = rows - rr;
     if (mr <= 0) return GPX_OK;
-    // tall columns (the bulk-bound phase of a large factorisation: no hurry, the machine is full) on 64x64 tiles,
-    // which move half the operand bytes per flop; the one-pass 32x32 tiles are for latency.  The choice follows the
-    // STEP (rows below block row k+2), not the launch: a column whose update starts one block lower in one hand-over
-    // mode ("diagonal block in the band kernel") must get the same tile routine -- the same bits -- in every mode.
-    GemmLaunch t = c.update(rr, mr, cfirst, ncol, kfirst, npan, !(h->la_rows > 0 && rows - (k + 2) * nb >= h->la_rows));
+    GemmLaunch t = c.update(rr, mr, cfirst, ncol, kfirst, npan, col_small(k));
     if (last && attach) { t.stop_event = h->ev_far[(size_t)k]; far_attached = true; }
     if (lp_flag && k == nblk - 2 && cfirst == nblk - 1) t.signal = flagsS + (nblk - 1);   // the last border panel waits for these tiles (chain stream)
     if (raise_far) { t.signal = flagsF + k; t.signal_m = nb; }   // the band kernel of step k+1 waits for the tiles of the first block row
@@ -505,11 +541,14 @@ struct SplitSchedule {
       if (dib[(size_t)(k + 1)]) {
         // column k+1 alone carries the hand-over to the chain; column k+2 from BELOW its diagonal block, behind the
         // wait for the bulk launch (the band kernel of step k+1 applies panel k to that block itself)
-        GPX_RET(col_update(k, k + 1, 1, k, 1, true, 0, far_flag[(size_t)k] != 0));
+        // far_flag[k]: block (k+2,k+1) belongs to row 2 of this step's band kernel; both updates start at block row k+3 and
+        // publish their first block row to row 2 of the NEXT band kernel
+        const bool rf = far_flag[(size_t)k] != 0;
+        GPX_RET(col_update(k, k + 1, 1, k, 1, true, rf ? 1 : 0, rf));
         if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
         far_attached = true;   // recorded (or attached) already: not again behind the second column
         if (col2_in_bulk) GPX_RET(q_wait_for_bulk());
-        GPX_RET(col_update(k, k + 2, 1, k, 1, false, 1));
+        GPX_RET(col_update(k, k + 2, 1, k, 1, false, 1, rf));
       } else if (ncb > 1 && npan2 > 1) {
         // grouped phases: column k+1 (whose last bulk update Q waited for a step ago) needs no bulk update to finish,
         // only column k+2 does
@@ -536,6 +575,8 @@ struct SplitSchedule {
     prof_begin(h, Q, GPX_STAGE_LOOKAHEAD, B * 2.0 * entries * t.K, B * 8.0 * (2.0 * entries + (double)(bm + nc) * t.K));
     GPX_RET(launch_gemm_nt(h, Q, t));
     prof_end(h, Q);
+    GPX_HIP_CHECK(h, hipEventRecord(h->ev_near, Q));
+    near_step = k;
     return GPX_OK;
   }
 

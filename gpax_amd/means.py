@@ -17,6 +17,14 @@ class Mean(Prior):
     def _mean_function(self, x, **params):
         raise NotImplementedError
 
+    def _mean_grad(self, x, **params):
+        """Optional: exact derivatives of the mean vector with respect to its learnable parameters, as a dict
+        ``name -> dm/dtheta`` of shape ``(N,)`` (scalar parameter) or ``(plate, N)``.  The reference gets them from
+        ``jax.grad`` through ``_mean_function`` (gpax/means.py:61-63 under the NUTS potential, gpax/gp.py:145-151); here
+        ``log_marginal_and_grad`` contracts them with ``alpha = K^-1 (y - m)``.  Names missing from the dict (or a
+        ``None`` return, the default) fall back to central differences."""
+        return None
+
     def sample_prior(self, x, rng=None):
         rng = rng if rng is not None else state.get_rng_key()[1]
         return self.__call__(x, **self.sample_parameters(rng))

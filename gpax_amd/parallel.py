@@ -63,26 +63,12 @@ def gather_draws(local, n_items, group=None):
     return full
 
 
-def map_draws(fn, n_items, group=None):
-    """``[fn(i) for i in range(n_items)]`` with the draws sharded over the ranks; ``fn`` returns a tuple of
-    arrays.  Returns a tuple of stacked arrays, identical on every rank."""
-    rank, ws = world()
-    mine = [fn(i) for i in partition_draws(n_items, rank, ws)]
-    n_out = None
-    if mine:
-        n_out = len(mine[0])
-    if ws > 1:
-        import torch.distributed as dist
-
-        counts = [None] * ws
-        dist.all_gather_object(counts, n_out, group=group)
-        n_out = next(c for c in counts if c is not None)
-    return tuple(gather_draws([m[k] for m in mine], n_items, group) for k in range(n_out))
-
-
 def map_draws_batched(fn_batch, n_items, group=None):
-    """Like ``map_draws`` for a function that takes ALL of a rank's draw indices at once (the HIP path runs them as one
-    batched schedule, ``gpx_sample_batch``) and returns a tuple of arrays stacked over those draws."""
+    """The vmap over hyper-parameter draws, sharded: ``fn_batch`` takes ALL of a rank's draw indices at once (the HIP path
+    runs them as one batched schedule, ``gpx_sample_batch``) and returns a tuple of arrays stacked over those draws;
+    returns a tuple of arrays stacked over all ``n_items`` draws in draw order, identical on every rank.  A rank that
+    owns no draw (fewer draws than ranks) does not call ``fn_batch`` and learns the number and shapes of the outputs
+    from the others."""
     rank, ws = world()
     idx = partition_draws(n_items, rank, ws)
     outs = fn_batch(idx) if idx else None

@@ -185,7 +185,10 @@ int gpx_sample_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* para
  *   GPX_ACQ_EI : param = y_max;  u = (mu - y_max) / sd;  sd * pdf(u) + (mu - y_max) * cdf(u)
  *   GPX_ACQ_UCB: param = beta;   mu + sqrt(beta + 1e-12) * sd  (beta = inf: sd, beta = 0: mu)
  * acq_out (m) optional; argmax_out / best_out: first index of the largest value and that value (what
- * _optimize_halton keeps, gpax/acquisition.py:211-216). */
+ * _optimize_halton keeps, gpax/acquisition.py:211-216).
+ * The resident (mean, var) is dropped by gpx_set_train / gpx_set_test / every new factorisation / gpx_lml_grad
+ * (GPX_ERR_STATE until the next posterior).  The factorisation's info word is read with the result: > 0 is returned as is
+ * (non-PD factor: the values are NaN), a timed-out in-kernel hand-over as GPX_ERR_RETRY (repeat the posterior call). */
 #define GPX_ACQ_EI 0
 #define GPX_ACQ_UCB 1
 int gpx_acquisition(gpx_handle* h, int32_t kind, double param, double mu_scale, double mu_shift, double sd_scale,

@@ -36,11 +36,16 @@ def _worker(rank, ws, port, n_items, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     try:
-        def fn(i):  # stands in for one complete gram+factor+posterior of draw i
-            rng = np.random.default_rng(1000 + i)
-            return rng.standard_normal(5) + i, np.full((2, 3), float(i))
+        calls = []
 
-        mu, y = parallel.map_draws(fn, n_items)
+        def fn_batch(idx):  # stands in for ONE batched schedule over this rank's draws (gpx_sample_batch)
+            calls.append(list(idx))
+            mu = np.stack([np.random.default_rng(1000 + i).standard_normal(5) + i for i in idx])
+            return mu, np.stack([np.full((2, 3), float(i)) for i in idx])
+
+        mu, y = parallel.map_draws_batched(fn_batch, n_items)
+        # one call with all of the rank's draws -- or none at all when the rank owns no draw
+        assert calls == ([parallel.partition_draws(n_items, rank, ws)] if parallel.partition_draws(n_items, rank, ws) else [])
         q.put((rank, mu, y))
         dist.barrier()
     finally:
@@ -48,7 +53,9 @@ def _worker(rank, ws, port, n_items, q):
 
 
 @pytest.mark.parametrize("n_items", [7, 2, 1])
-def test_map_draws_world_size_2_matches_serial(n_items):
+def test_map_draws_batched_world_size_2_matches_serial(n_items):
+    """``parallel.map_draws_batched`` (what ``GaussianProcess._sample_over_hps`` calls) over two gloo ranks, incl.
+    ``n_items = 1``: rank 1 owns nothing, never calls ``fn_batch`` and still returns the full result."""
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
@@ -68,5 +75,5 @@ def test_map_draws_world_size_2_matches_serial(n_items):
 
 
 def test_single_process_path_is_identity():
-    mu, = parallel.map_draws(lambda i: (np.array([i, 2.0 * i]),), 4)
+    mu, = parallel.map_draws_batched(lambda idx: (np.array([[i, 2.0 * i] for i in idx]),), 4)
     assert np.array_equal(mu, np.array([[0, 0], [1, 2], [2, 4], [3, 6.0]]))

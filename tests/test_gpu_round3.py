@@ -1,0 +1,223 @@
+"""Round-3 parity cases (``-m gpu``, through the C ABI): the sizes ``ExactGP.fit()`` / ``sample()`` / the C5 acquisition step are
+benchmarked at, which the earlier suites reached only with finiteness checks.
+
+  * ``gpx_lml_grad`` at N = 2048 / 4096 against the oracle's closed form, incl. a run whose K^-1 accumulation goes through
+    GROUPED (K = 256 / 512) bulk phases and `grad_reduce_kernel` over > 100 tiles (gpax/gp.py:515-530 is what it replaces);
+  * ``gpx_sample_batch`` with M = 1024 / 2500 test points: the M x M posterior covariance is factorised by the split-panel
+    schedule (>= 8 block columns), as C5's ``sample()`` would (gpax/gp.py:314-338, 382-391);
+  * ``gpx_acquisition`` at C5 scale (N = 8192, 10 000 candidates) against the host formulae on ``gpx_posterior`` outputs
+    (gpax/acquisition.py:260-266, 291-298);
+  * the factor-cache interleaving of ADVICE round 2 (conditioned predict / prior-only sample / the same predict again).
+"""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL_GRAD_REL = 1e-7    # of the largest gradient component (a sum of N^2 terms G_ij dK_ij, |K^-1| ~ cond(K))
+TOL_LOGP_REL = 1e-10
+TOL_ALPHA_REL = 1e-7
+
+
+@pytest.fixture(scope="module")
+def core():
+    import gpax_amd
+
+    c = gpax_amd.Core(0)
+    yield c
+    c.close()
+
+
+def _problem(n, d, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (n, d))
+    y = np.sin(3.0 * x.sum(1) / np.sqrt(d)) + 0.1 * rng.standard_normal(n)
+    return x, (y - y.mean()) / (y.std() + 1e-8) - 1.0, rng
+
+
+@pytest.mark.parametrize("kind,n,d,ard,noise,opts", [
+    (0, 2048, 4, True, 0.02, {}),                                  # 16 block columns, default grouping (ungrouped)
+    (0, 2048, 4, True, 0.02, {"pair_min": 4, "quad_min": 8}),      # the same problem through K = 512 and K = 256 passes
+    (1, 4096, 3, False, 0.05, {}),                                 # the size profiles/*_fit_bench.txt quotes (2.3 ms per call)
+    (0, 4096, 2, False, 0.01, {"pair_min": 6, "quad_min": 12}),
+])
+def test_lml_grad_matches_oracle_at_fit_sizes(core, kind, n, d, ard, noise, opts):
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, r, rng = _problem(n, d, seed=7 * n + d)
+    k_length = rng.uniform(0.7, 1.4, d) if ard else np.array([0.9])
+    k_scale = 1.2
+    saved = {k: core.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            core.set_option(k, v)
+        core.set_train(x)
+        p = gpax_amd.make_params(kind, k_scale, k_length, None, np.array([noise]), 1e-6, True)
+        info, logp, grads, alpha = core.lml_grad(p, r)
+        info2, logp2, grads2, alpha2 = core.lml_grad(p, r)     # repeatable bit for bit (fixed-order reduction)
+    finally:
+        for k, v in saved.items():
+            core.set_option(k, v)
+    assert info == 0 and info2 == 0
+    assert logp == logp2 and np.array_equal(alpha, alpha2) and all(np.array_equal(grads[k], grads2[k]) for k in grads)
+    logp_ref, g_ref, alpha_ref = orc.lml_grad(kind, x, r, k_scale, k_length, None, noise, 1e-6)
+    assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+    assert np.abs(alpha - alpha_ref).max() <= TOL_ALPHA_REL * np.abs(alpha_ref).max()
+    scale = max(np.abs(v).max() for v in g_ref.values())
+    assert set(grads) == set(g_ref)
+    for name, ref in g_ref.items():
+        assert grads[name].shape == ref.shape, name
+        assert np.abs(grads[name] - ref).max() <= TOL_GRAD_REL * scale, (name, grads[name], ref)
+
+
+def test_lml_grad_grouping_does_not_move_the_result_beyond_rounding(core):
+    """Grouped and ungrouped K^-1 accumulation are different summation orders of the same sum: equal to ~1e-12 relative."""
+    import gpax_amd
+
+    x, r, rng = _problem(2048, 4, seed=3)
+    core.set_train(x)
+    p = gpax_amd.make_params(0, 1.0, np.array([1.1]), None, np.array([0.03]), 1e-6, True)
+    _, logp_a, g_a, _ = core.lml_grad(p, r)
+    saved = {k: core.get_option(k) for k in ("pair_min", "quad_min")}
+    try:
+        core.set_option("pair_min", 2); core.set_option("quad_min", 4)
+        _, logp_b, g_b, _ = core.lml_grad(p, r)
+    finally:
+        for k, v in saved.items():
+            core.set_option(k, v)
+    scale = max(np.abs(v).max() for v in g_a.values())
+    assert abs(logp_a - logp_b) <= 1e-11 * abs(logp_a)
+    assert all(np.abs(g_a[k] - g_b[k]).max() <= 1e-9 * scale for k in g_a)
+
+
+@pytest.mark.parametrize("conditioned", [True, False])
+@pytest.mark.parametrize("n,m,d,kind,b", [(300, 1024, 2, 0, 2), (500, 2500, 2, 1, 2)])
+def test_device_resident_sampling_with_a_split_schedule_covariance_factor(core, conditioned, n, m, d, kind, b):
+    """``gpx_sample_batch`` where the M x M posterior (or prior) covariance needs the split-panel schedule (8 and 20 block
+    columns): mean, sd and ``mean + eps chol(cov)^T`` against the oracle with the SAME eps."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(n + m)
+    x, y, xn, _ = orc.synthetic_problem(n, d, m, seed=n, kind=kind)
+    draws = [dict(k_scale=np.array([float(np.exp(0.2 * rng.standard_normal()))]), k_length=np.exp(0.2 * rng.standard_normal(1)),
+                  k_noise=np.array([0.01 + 0.02 * rng.uniform()]), k_jitter=np.array([1e-6])) for _ in range(b)]
+    plist = [gpax_amd.make_params(kind, q["k_scale"], q["k_length"], None, q["k_noise"], q["k_jitter"]) for q in draws]
+    nsamp = 3
+    eps = rng.standard_normal((b, nsamp, m))
+    r = np.stack([y - 1.0] * b)
+    m_new = np.ones((b, m))
+    new_noise = np.array([q["k_noise"][0] for q in draws])     # observation_noise=True: cov >= k_noise on the diagonal
+    core.set_train(x)
+    core.set_test(xn)
+    info, mean, sd, smp = core.sample_batch(plist, r if conditioned else None, m_new, new_noise, eps, conditioned=conditioned)
+    assert (info == 0).all() and smp.shape == (b, nsamp, m)
+    for i, q in enumerate(draws):
+        if conditioned:
+            mean_ref, cov_ref = orc.mean_and_covariance(kind, x, y, xn, dict(q), observation_noise=True)
+        else:
+            mean_ref, cov_ref = orc.mean_and_covariance_unconditioned(kind, xn, dict(q), observation_noise=True)
+            mean_ref = np.broadcast_to(mean_ref, (m,))
+        assert np.abs(mean[i] - mean_ref).max() <= 1e-8
+        assert np.abs(sd[i] - np.sqrt(np.diag(cov_ref))).max() <= 1e-8
+        ref = mean_ref[None, :] + eps[i] @ orc.cholesky_lower(cov_ref).T
+        # chol(cov) amplifies differences in cov by ~1/sqrt(lambda_min(cov)) <= 1/sqrt(k_noise) = 10
+        assert np.abs(smp[i] - ref).max() <= 1e-6, np.abs(smp[i] - ref).max()
+
+
+def test_acquisition_epilogue_at_c5_scale(core):
+    """BASELINE.json configs[4] at full size: Matern-5/2, d = 2, N = 8192, structured (piecewise) prior mean, 10 000
+    candidates in one posterior call; the device EI / UCB values and arg-max against the oracle's formulae
+    (gpax/acquisition.py:260-266, 291-298) evaluated on the host from the SAME call's (mean, var)."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    n, m = 8192, 10000
+    rng = np.random.default_rng(7)
+    x = rng.uniform(0.0, 3.0, (n, 2))
+    xn = rng.uniform(0.0, 3.0, (m, 2))
+    y = orc.piecewise_mean(x) + 0.05 * rng.standard_normal(n)
+    core.set_train(x)
+    core.set_test(xn)
+    p = gpax_amd.make_params(gpax_amd.MATERN52, 1.0, 1.0, None, np.array([0.01]), 1e-6, True)
+    info, logp, mean, var = core.fit_predict(p, y - orc.piecewise_mean(x), orc.piecewise_mean(xn), 0.0)
+    assert info == 0 and np.isfinite(logp) and (var > 0).all()
+    sd = np.sqrt(var)
+    y_max = float(y.max())
+    for kind, param, want in ((0, y_max, orc.expected_improvement(mean, sd, y_max)), (1, 4.0, orc.upper_confidence_bound(mean, sd, 4.0))):
+        vals, idx, best = core.acquisition(kind, param)
+        tol = 1e-11 * max(1.0, np.abs(want).max())
+        assert np.abs(vals - want).max() <= tol
+        assert idx == int(np.argmax(want)) and abs(best - want.max()) <= tol
+    # an affine output transform folded in (Normalize-style): mu = 3 mean - 2, sd = 3 sd
+    vals, idx, best = core.acquisition(0, y_max, 3.0, -2.0, 3.0)
+    want = orc.expected_improvement(3.0 * mean - 2.0, 3.0 * sd, y_max)
+    assert np.abs(vals - want).max() <= 1e-11 * max(1.0, np.abs(want).max()) and idx == int(np.argmax(want))
+    # the resident (mean, var) is dropped by whatever rewrites the result block
+    core.set_test(xn[:10])
+    with pytest.raises(gpax_amd.GpxError):
+        core.acquisition(0, y_max)
+
+
+def test_prior_only_sample_between_two_cached_predicts():
+    """a prior-only model's ``sample()`` on the shared handle between two identical conditioned
+    ``predict(fast=True)`` calls of another model used to leave that model's factor-cache key in place while
+    ``gpx_sample_batch`` had dropped the factor (GPX_ERR_STATE on the third call)."""
+    import gpax_amd
+    from gpax_amd import state
+
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (200, 2))
+    y = np.sin(2 * x[:, 0]) + 0.1 * rng.standard_normal(200)
+    xs = rng.uniform(-1, 1, (40, 2))
+    a = gpax_amd.ExactGP(kernel=gpax_amd.RBFKernel(), x=x, y=y)
+    b = gpax_amd.ExactGP(kernel=gpax_amd.RBFKernel(), hp_samples=3, gp_samples=2)      # prior only, same d
+    state.set_rng_key(5)
+    mu1, sd1 = a.predict(xs, fast=True)
+    state.set_rng_key(6)
+    s = b.sample(xs)
+    assert s.y.shape == (3, 2, 40)
+    state.set_rng_key(5)
+    mu2, sd2 = a.predict(xs, fast=True)
+    assert np.allclose(mu1, mu2, rtol=0, atol=1e-12) and np.allclose(sd1, sd2, rtol=0, atol=1e-12)
+
+
+def test_exact_mean_gradient_hook_against_central_differences():
+    """``Mean._mean_grad`` (the derivatives jax.grad gives the reference for the structured mean of
+    examples/04_Structured_GP.ipynb cell 10): the beta-derivatives agree with central differences of the mean function,
+    and d/dt is exactly 0 where central differences of the step are noise."""
+    import importlib.util
+    import os
+
+    import gpax_amd
+
+    spec = importlib.util.spec_from_file_location("structured_gp", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "structured_gp.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(1)
+    x = rng.uniform(0.05, 3.0, (60, 1))
+    mean = mod.PiecewiseMeanPrior()
+    y = mean(x, m_t=1.7, m_beta1=4.5, m_beta2=2.5) + rng.normal(0.0, 0.1, 60)
+    gp = gpax_amd.ExactGP(kernel=gpax_amd.MaternKernel(), mean=mean, input_transform=None, output_transform=None, x=x, y=y)
+    params = {"k_scale": np.array([1.0]), "k_length": np.array([0.8]), "k_noise": np.array([0.02]), "k_jitter": np.array([1e-6]),
+              "m_t": np.array([1.6]), "m_beta1": np.array([4.0]), "m_beta2": np.array([2.2])}
+    logp, g = gp.log_marginal_and_grad(params)
+    assert np.isfinite(logp) and g["m_t"].shape == (1,) and g["m_t"][0] == 0.0
+    for name in ("m_beta1", "m_beta2", "k_length", "k_scale"):
+        h = 1e-6
+        up, dn = dict(params), dict(params)
+        up[name] = params[name] + h
+        dn[name] = params[name] - h
+        fd = (gp.log_marginal(up) - gp.log_marginal(dn)) / (2 * h)
+        assert abs(fd - g[name][0]) <= 1e-5 * max(1.0, abs(fd)), (name, fd, g[name])
+
+    class NoHook(mod.PiecewiseMeanPrior):
+        def _mean_grad(self, x, **params):
+            return None
+
+    gp2 = gpax_amd.ExactGP(kernel=gpax_amd.MaternKernel(), mean=NoHook(), input_transform=None, output_transform=None, x=x, y=y)
+    _, g2 = gp2.log_marginal_and_grad(params)      # central differences of the host mean function
+    assert abs(g2["m_beta1"][0] - g["m_beta1"][0]) <= 1e-5 * max(1.0, abs(g["m_beta1"][0]))
+    assert abs(g2["m_beta2"][0] - g["m_beta2"][0]) <= 1e-5 * max(1.0, abs(g["m_beta2"][0]))
