@@ -3,7 +3,8 @@
 
 For every block step k the band kernel's first phase (S = A_{k+1,k} W_k^T) can start when ALL of these have arrived:
   W     potrf_diag(k) has published W_k                      (in-kernel flag; the time its flag went up, after its last instruction)
-  Qpub  the panel stream's update of column k at step k-1 has published its first block row (in-kernel counter)
+  Qpub  the panel stream's column updates of step k-1 have published their first block row (in-kernel counter; since round 3
+        only row 2 of the band kernel waits for it)
   bulk  the bulk launch that last wrote block (k+1,k+1) has ended (stream-level event in front of the band launch)
   res   the band kernel itself is resident                    (its launch, behind whatever its stream waits for)
 The table gives each arrival relative to potrf_diag(k)'s end, names the LAST one, and the gap to potrf_diag(k+1)'s start.
@@ -93,13 +94,17 @@ for k in steps:
     # resident: the first kind-6 record of this band kernel = the last kind-6 record with beta == (phase-0 ? 1 : 0) before S
     res_c = [t for t, kd, beta in band_seq if kd == 6 and (S is None or t <= S) and t >= potrf_start[k] - 60.0]
     res = res_c[0] if res_c else None
-    # Qpub: the column update of step k-1 (column k below its diagonal block): M = rows_total - (k+1) nb, N = nb
-    qp = [g for g in gemms if g["role"] == "col" and g["N"] == nb and g["M"] == rows_total - (k + 1) * nb and g["pub"]]
-    qpub = qp[-1]["pub"] if qp else None
+    # Qpub: the column updates of step k-1 that publish their first block row (round 2: column k from block row k+1,
+    # M = rows_total - (k+1) nb; round 3: columns k and k+1 from block row k+2, M = rows_total - (k+2) nb, which feed
+    # row 2 of the band kernel -- NOT on the critical path: listed for the slack, counted as a dependency of S only
+    # with CP_QPUB_CRITICAL=1, i.e. for the round-2 library)
+    qp = [g for g in gemms if g["role"] == "col" and g["N"] == nb and g["M"] in (rows_total - (k + 1) * nb, rows_total - (k + 2) * nb)
+          and g["pub"] and g["start"] < nxt]
+    qpub = max(g["pub"] for g in qp) if qp else None
     # bulk: the latest bulk launch that started before S and whose first column is <= k+1 (cf = (rows_total - M) / nb)
     bl = [g for g in gemms if g["role"] == "bulk" and g["end"] and (rows_total - g["M"]) // nb <= k + 1 and (S is None or g["start"] < S)]
     bulk = bl[-1]["end"] if bl else None
-    arr = {"W": potrf_pub.get(k, pe), "Qpub": qpub, "bulk": bulk, "res": res}
+    arr = {"W": potrf_pub.get(k, pe), "Qpub": qpub if os.environ.get("CP_QPUB_CRITICAL") else None, "bulk": bulk, "res": res}
     have = {kk: v for kk, v in arr.items() if v is not None}
     last = max(have, key=lambda kk: have[kk]) if have else "?"
     last_count[last] = last_count.get(last, 0) + 1
