@@ -257,7 +257,7 @@ extern "C" int gpx_create(int device_id, gpx_handle** out) {
   // (rocprofv3 --pmc) serialises every dispatch, so fall back to kernel-boundary hand-overs under it
   if (getenv("ROCPROF_COUNTER_COLLECTION") || getenv("ROCPROF_COUNTERS")) h->resident = 0;
   const char* env;
-  if ((env = getenv("GPX_RESIDENT"))) h->resident = std::min(std::max(atoi(env), 0), 2);
+  if ((env = getenv("GPX_RESIDENT"))) h->resident = std::min(std::max(atoi(env), 0), 3);
   *out = h;
   return GPX_OK;
 }
@@ -318,6 +318,7 @@ static int* option_slot(gpx_handle* h, const char* name) {
   if (!strcmp(name, "split_min_blocks")) return &h->split_min_blocks;
   if (!strcmp(name, "la_rows")) return &h->la_rows;
   if (!strcmp(name, "batch_group")) return &h->batch_group;
+  if (!strcmp(name, "chain_overlap")) return &h->chain_overlap;
   if (!strcmp(name, "debug_force_timeout")) return &h->debug_force_timeout;
   return nullptr;
 }
@@ -335,7 +336,7 @@ extern "C" int gpx_set_option(gpx_handle* h, const char* name, int64_t value) {
   if (!slot) { gpx_set_error(h, std::string("unknown option ") + name); return GPX_ERR_ARG; }
   int64_t v = std::max<int64_t>(value, 0);
   if (!strcmp(name, "lookahead") || !strcmp(name, "debug_force_timeout")) v = v != 0;
-  if (!strcmp(name, "resident")) v = std::min<int64_t>(v, 2);
+  if (!strcmp(name, "resident")) v = std::min<int64_t>(v, 3);
   if (!strcmp(name, "split_min_blocks")) v = std::max<int64_t>(v, 2);
   *slot = (int)v;
   return GPX_OK;

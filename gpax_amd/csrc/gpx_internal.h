@@ -142,10 +142,30 @@ struct PotrfLaunch {
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;   // resident start: sleep until *wait_flag >= wait_count
   unsigned* done_flag = nullptr;                                   // raised behind the last store of W
   unsigned long long wait_ticks = 25000000ull;                     // bound of the resident wait (100 MHz ticks: 0.25 s)
+  int any_order = 0;                                               // launch without the queue barrier (hipExtAnyOrderLaunch)
   int batch = 1;                                                   // blockIdx.x = draw
   int64_t sA = 0, sL = 0, sW = 0, s_info = 0, s_flag = 0;
 };
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& p);
+// every diagonal block [k0, k1) of the factorisation in one launch: one resident workgroup per draw walks down the diagonal
+// (block k at A + k nb (lda + 1), W_k at W + k nb^2), handing over through flagsU / flagsW (potrf.hip: potrf_chain_kernel)
+struct PotrfChainLaunch {
+  int nb = 128;
+  const double* A = nullptr; int64_t lda = 0;   // block 0
+  double* L = nullptr; int64_t ldl = 0;
+  double* W = nullptr;
+  int* info = nullptr;
+  const unsigned* flagsU = nullptr; unsigned* flagsW = nullptr;
+  int k0 = 0, k1 = 0, raise_until = 0, force_k = -1;
+  unsigned wait_count = 0;
+  unsigned long long wait_ticks = 25000000ull;
+  int batch = 1;
+  int64_t sA = 0, sL = 0, sW = 0, s_info = 0, s_flag = 0;
+};
+int launch_potrf_chain(gpx_handle* h, hipStream_t s, const PotrfChainLaunch& p);
+// one wave per draw that sleeps until *flag >= count: the kernel boundary behind it releases the next kernel of the stream
+int launch_chain_relay(gpx_handle* h, hipStream_t s, const unsigned* flag, unsigned count, int* info, int batch, int64_t s_flag,
+                       int64_t s_info);
 
 // y[0:ncols) = beta*y + alpha * x[0:nrows)^T A[0:nrows, 0:ncols)
 int launch_gemv_t(gpx_handle* h, hipStream_t s, const double* A, int64_t lda, int nrows, int64_t ncols,
@@ -263,13 +283,16 @@ struct gpx_handle {
   int nb = 128;
   bool nb_auto = true;   // no explicit "nb" option: 64 for n <= 64 (potrf_diag<64> runs 12 us, <128> 29 us), else 128
   int lookahead = 1;     // 0: everything on one stream; 1: the split-panel schedule from split_min_blocks block columns on
-  int resident = 2;      // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
-                         // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag)
+  int resident = 3;      // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
+                         // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag);
+                         // 3 = also ONE potrf_diag workgroup per draw for the whole factorisation (it keeps its CU)
   int pair_min = 28;     // pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 40;     // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
   int split_min_blocks = 3;   // the split-panel (multi-stream) schedule runs from this many block columns; below, one stream
   int la_rows = 3072;    // look-ahead column updates use 64x64 tiles while at least this many rows remain below; 0 = never
   int batch_group = 4;   // batches of >= 4 draws: bulk updates grouped g panels at a time throughout (0: the single-draw thresholds)
+  int chain_overlap = 0;   // potrf_diag(k) is launched WITHOUT the queue barrier (it may start while potrf_diag(k-1) runs: its order is
+                           // carried by the device flags) in the last `chain_overlap` block columns; 0 = never
   int debug_force_timeout = 0;   // test hook: the next factorisation's first resident wait gives up at once (info = -7)
 
   // resident inputs (x and x_new are shared by the draws of a batch; r, m_new, hyp, noise are per draw)

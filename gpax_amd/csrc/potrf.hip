@@ -648,6 +648,88 @@ __global__ __launch_bounds__(NWAVES * 64) void potrf_diag_kernel(PotrfArgs p) {
                  p.done_flag ? p.done_flag + z * p.s_flag : nullptr, p.wait_ticks, sm);
 }
 
+// ---- the whole chain of diagonal blocks in ONE launch ("resident" = 3) ---------------------------------------------------
+// potrf_diag needs a whole CU (149 KB of LDS, 8 waves x 233 VGPRs).  Launched per block -- even a step early -- the next one
+// has to be GIVEN a CU while a bulk update saturates the chip (three 37-KB workgroups per CU, refilled one by one as they
+// finish): measured with the timeline build (profiles/r03_critical_path_row2.txt), potrf_diag(k+1) became resident 18-39 us
+// after potrf_diag(k) had ended in the first half of an N = 4096 factorisation, 4 us in the last steps -- with every one of
+// its inputs long there.  (hipExtAnyOrderLaunch, which would let it become resident beside its predecessor, is ignored on
+// gfx950: tools/anyorder_probe.)  One workgroup per draw therefore keeps its CU for the whole factorisation and walks
+// down the diagonal: block k waits for flagsU[k-1] (the band kernel's tiles of A_kk), factors, publishes W_k (write-through)
+// and raises flagsW[k].  The band kernel polls flagsW[k] as before; the panel stream, which used to wait for this kernel's
+// completion event, gets a one-wave relay kernel that sleeps on the same flag (chain_relay_kernel).  L_kk itself has no
+// reader before the end of the factorisation.
+struct PotrfChainArgs {
+  const double* A; int64_t lda; double* L; int64_t ldl; double* W; int* info;
+  const unsigned* flagsU; unsigned* flagsW;
+  int k0, k1;             // blocks [k0, k1)
+  int raise_until;        // flagsW[k] is raised for k < raise_until
+  int force_k;            // test hook: block force_k waits for an impossible count (gives up at once: info = -7)
+  unsigned wait_count;
+  unsigned long long wait_ticks;
+  int64_t sA, sL, sW, s_info, s_flag;
+};
+
+template <int NB, int NWAVES>
+__global__ __launch_bounds__(NWAVES * 64) void potrf_chain_kernel(PotrfChainArgs p) {
+  constexpr int NT = NB / 16, NTRI = NT * (NT + 1) / 2;
+  static_assert(NWAVES == NT, "potrf_diag: one wave per block row");
+  __shared__ double sm[NT * NT * 256 + NT * DT_STRIDE + (NTRI + NT) / 2 + 2];
+  __shared__ int stop;
+  const int64_t z = blockIdx.x;
+  int* info = p.info + z * p.s_info;
+  for (int k = p.k0; k < p.k1; ++k) {
+    const int64_t off = (int64_t)k * NB;
+    const unsigned* wf = k >= 1 ? p.flagsU + (k - 1) + z * p.s_flag : nullptr;
+    unsigned* df = k < p.raise_until ? p.flagsW + k + z * p.s_flag : nullptr;
+    const bool forced = k == p.force_k && wf;
+    potrf_flow<NB, true>(p.A + z * p.sA + off * p.lda + off, p.lda, p.L + z * p.sL + off * p.ldl + off, p.ldl,
+                         p.W + z * p.sW + (int64_t)k * NB * NB, info, (int)off, wf, forced ? 0xffffffffu : p.wait_count, df,
+                         forced ? 2000ull : p.wait_ticks, sm);
+    // a wait that gave up (-7) or an internal error (-8): the remaining blocks would each wait their bound out
+    if (threadIdx.x == 0) stop = __hip_atomic_load(info, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0;
+    __syncthreads();   // also: every wave is done with the LDS image before the next block re-initialises it
+    if (stop) break;
+    __syncthreads();   // `stop` is rewritten by the next round
+  }
+}
+
+// One wave per draw: sleeps until *flag >= count, then ends -- the kernel boundary behind it is what releases the next
+// kernel of its stream (the panel of step k behind W_k).
+__global__ __launch_bounds__(64) void chain_relay_kernel(const unsigned* flag, unsigned count, int* info, int64_t s_flag, int64_t s_info,
+                                                         unsigned long long wait_ticks) {
+  flag += (int64_t)blockIdx.x * s_flag; info += (int64_t)blockIdx.x * s_info;
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < count) {
+      __builtin_amdgcn_s_sleep(8);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > wait_ticks) { atomicMin(info, -7); break; }
+    }
+  }
+}
+
+int launch_chain_relay(gpx_handle* h, hipStream_t s, const unsigned* flag, unsigned count, int* info, int batch, int64_t s_flag,
+                       int64_t s_info) {
+  hipLaunchKernelGGL(chain_relay_kernel, dim3((unsigned)batch), dim3(64), 0, s, flag, count, info, s_flag, s_info, 25000000ull);
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
+int launch_potrf_chain(gpx_handle* h, hipStream_t s, const PotrfChainLaunch& q) {
+  PotrfChainArgs p;
+  p.A = q.A; p.lda = q.lda; p.L = q.L; p.ldl = q.ldl; p.W = q.W; p.info = q.info;
+  p.flagsU = q.flagsU; p.flagsW = q.flagsW; p.k0 = q.k0; p.k1 = q.k1; p.raise_until = q.raise_until; p.force_k = q.force_k;
+  p.wait_count = q.wait_count; p.wait_ticks = q.wait_ticks;
+  p.sA = q.sA; p.sL = q.sL; p.sW = q.sW; p.s_info = q.s_info; p.s_flag = q.s_flag;
+  if (q.batch < 1 || q.k1 <= q.k0 || !q.flagsU || !q.flagsW) { gpx_set_error(h, "potrf_chain: contract violated"); return GPX_ERR_ARG; }
+  const dim3 grid((unsigned)q.batch);
+  if (q.nb == 128) hipLaunchKernelGGL((potrf_chain_kernel<128, 8>), grid, dim3(512), 0, s, p);
+  else if (q.nb == 64) hipLaunchKernelGGL((potrf_chain_kernel<64, 4>), grid, dim3(256), 0, s, p);
+  else { gpx_set_error(h, "potrf_chain: nb must be 64 or 128"); return GPX_ERR_ARG; }
+  GPX_HIP_CHECK(h, hipGetLastError());
+  return GPX_OK;
+}
+
 int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& q) {
   PotrfArgs p;
   p.A = q.A; p.lda = q.lda; p.L = q.L; p.ldl = q.ldl; p.W = q.W; p.info = q.info; p.col0 = q.col0;
@@ -655,14 +737,15 @@ int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& q) {
   p.sA = q.sA; p.sL = q.sL; p.sW = q.sW; p.s_info = q.s_info; p.s_flag = q.s_flag;
   if (q.batch < 1) { gpx_set_error(h, "potrf_diag: batch < 1"); return GPX_ERR_ARG; }
   const dim3 grid((unsigned)q.batch);
+  const unsigned fl = q.any_order ? hipExtAnyOrderLaunch : 0u;
   switch (q.nb) {
     case 64:
-      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, true>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
-      else hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, false>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
+      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, true>), grid, dim3(256), 0, s, nullptr, q.stop_event, fl, p);
+      else hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, false>), grid, dim3(256), 0, s, nullptr, q.stop_event, fl, p);
       break;
     case 128:
-      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, true>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
-      else hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, false>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
+      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, true>), grid, dim3(512), 0, s, nullptr, q.stop_event, fl, p);
+      else hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, false>), grid, dim3(512), 0, s, nullptr, q.stop_event, fl, p);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

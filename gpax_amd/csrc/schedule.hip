@@ -189,7 +189,7 @@ struct SplitSchedule {
   int64_t nb, nblk;
   double B;                       // draws per launch (profiling: flops and bytes scale with it)
   hipStream_t P, P2, Q, T;
-  bool resident, chain2, fuse_band, kinv, attach, use_dib, lp_flag = false;
+  bool resident, chain2, fuse_band, kinv, attach, use_dib, persistent, lp_flag = false;
   unsigned n_signal;
   unsigned *flagsU, *flagsW, *flagsS, *flagsF, *flagsS2, *flagsD;
   // "diagonal block in the band kernel" (fused band kernel, ungrouped steps).  The column update of step j used to
@@ -236,6 +236,7 @@ struct SplitSchedule {
     P2 = resident ? h->s_main2 : P;
     chain2 = resident && h->resident >= 2;
     fuse_band = chain2;
+    persistent = chain2 && h->resident >= 3;   // ONE potrf_diag workgroup per draw for the whole factorisation (potrf.hip)
     kinv = h->kinv_U != nullptr;
     // completion events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL stopEvent) except under
     // per-launch profiling, where they are recorded behind the kernel as usual
@@ -341,12 +342,24 @@ struct SplitSchedule {
       // the panel stream: one wrong posterior in ~200 runs of the test suite.)
       GPX_HIP_CHECK(h, hipStreamWaitEvent(PD, h->ev_far[(size_t)(k - 1)], 0));
     }
-    {
+    if (persistent) {
+      if (k == 0) {
+        PotrfChainLaunch q;
+        q.nb = (int)nb; q.A = c.A(0, 0); q.lda = c.ld; q.L = c.L(0, 0); q.ldl = c.ld; q.W = c.W(0); q.info = h->d_info;
+        q.flagsU = flagsU; q.flagsW = flagsW; q.k0 = 0; q.k1 = (int)nblk; q.raise_until = (int)nblk; q.force_k = (int)force_timeout_at;
+        q.wait_count = n_signal;
+        q.batch = c.M.batch; q.sA = c.M.sA; q.sL = c.M.sA; q.sW = c.M.sW; q.s_info = c.s_info; q.s_flag = h->s_flags;
+        prof_begin(h, PD, GPX_STAGE_POTRF_DIAG, B * (double)nblk * nb * nb * nb / 3.0 * 2.0, B * (double)nblk * 3.0 * 8.0 * nb * nb);
+        GPX_RET(launch_potrf_chain(h, PD, q));
+        prof_end(h, PD);
+      }
+    } else {
       PotrfLaunch p = c.potrf(k);
       if (need_w && attach) p.stop_event = h->ev_w[(size_t)k];
       if (resident && k >= 1) { p.wait_flag = flagsU + (k - 1); p.wait_count = n_signal; }
       if (chain2 && need_w && k + 1 < nblk) p.done_flag = flagsW + k;
       if (k == force_timeout_at && p.wait_flag) { p.wait_count = 0xffffffffu; p.wait_ticks = 2000ull; }
+      if (chain2 && p.wait_flag && k >= 2 && nblk - k <= h->chain_overlap) p.any_order = 1;
       prof_begin(h, PD, GPX_STAGE_POTRF_DIAG, B * (double)nb * nb * nb / 3.0 * 2.0, B * 3.0 * 8.0 * nb * nb);
       GPX_RET(launch_potrf_diag(h, PD, p));
       prof_end(h, PD);
@@ -364,7 +377,7 @@ struct SplitSchedule {
       prof_end(h, PD);
       return GPX_OK;   // (the gradient path keeps its last panel on Q: the K^-1 update behind it belongs to T's sequence)
     }
-    if (!attach) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], PD));
+    if (!attach && !persistent) GPX_HIP_CHECK(h, hipEventRecord(h->ev_w[(size_t)k], PD));
     if (k + 1 >= nblk) return GPX_OK;
     const bool far_by_flag = k >= 1 && far_flag[(size_t)(k - 1)] != 0;
     if (k >= 1 && !far_by_flag) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, h->ev_far[(size_t)(k - 1)], 0));   // columns k, k+1 were brought up to date by Q at step k-1
@@ -443,7 +456,10 @@ struct SplitSchedule {
     const int64_t c0 = k * nb, r0 = c0 + nb, rows = c.rows_at(k), mrows = rows - r0;
     // (Starting the panel kernel resident too -- it would sleep on potrf_diag's flag instead of waiting ~8 us for the
     // cross-stream event -- crowds the bulk update with sleeping workgroups: 1.76 -> 1.81 ms, not used.)
-    GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
+    // W_k: the completion event of potrf_diag(k), or -- where one workgroup walks the whole diagonal -- a one-wave relay
+    // kernel that sleeps on flagsW[k]; the kernel boundary behind it releases the panel
+    if (persistent) GPX_RET(launch_chain_relay(h, Q, flagsW + k, 1u, h->d_info, c.M.batch, h->s_flags, c.s_info));
+    else GPX_HIP_CHECK(h, hipStreamWaitEvent(Q, h->ev_w[(size_t)k], 0));
     GemmLaunch g = c.panel(k, r0, mrows, c.L(r0, c0), c.ld, c.M.sA);
     if (k >= 1 && far_flag[(size_t)(k - 1)]) {
       // its first block row, A_{k+1,k}, was last written by row 2 of the band kernel of step k-1 (another stream): those

@@ -7,7 +7,8 @@ For every block step k the band kernel's first phase (S = A_{k+1,k} W_k^T) can s
         only row 2 of the band kernel waits for it)
   bulk  the bulk launch that last wrote block (k+1,k+1) has ended (stream-level event in front of the band launch)
   res   the band kernel itself is resident                    (its launch, behind whatever its stream waits for)
-The table gives each arrival relative to potrf_diag(k)'s end, names the LAST one, and the gap to potrf_diag(k+1)'s start.
+The table gives each arrival relative to potrf_diag(k)'s end, names the LAST one, when the band kernel's phases S and U
+started, when potrf_diag(k+1) became resident (pres: its first instruction, before its wait) and when it started (next).
 
     python tools/critical_path.py [N] [out.txt]
 """
@@ -32,6 +33,8 @@ rng = np.random.default_rng(0)
 x = rng.uniform(-1, 1, (n, d)); xn = rng.uniform(-1, 1, (m, d)); y = rng.standard_normal(n)
 core = gpax_amd.Core(0)
 lib = _lib.load()
+for kv in filter(None, os.environ.get("CP_OPTS", "").split(",")):   # e.g. CP_OPTS=chain_overlap=32,pair_min=24
+    core.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 core.set_train(x); core.set_test(xn); core.set_targets(y, np.ones(m))
 p = gpax_amd.make_params(0, 1.0, 1.0, None, np.array([0.0067]), 1e-6)
 for _ in range(8):
@@ -81,7 +84,7 @@ nblk = n // nb
 # "S started" (kind 3, beta 0) before potrf_start[k+1] and the first "resident" record after potrf_start[k] - 40 us
 steps = sorted(k for k in potrf_end if k + 1 in potrf_start)
 lines = []
-hdr = f"{'k':>3} {'potrf':>6} | arrivals relative to potrf_diag(k) end [us]: {'W':>5} {'Qpub':>7} {'bulk':>7} {'res':>7} | {'S':>6} {'U':>6} {'next':>6} | last to arrive"
+hdr = f"{'k':>3} {'potrf':>6} | arrivals relative to potrf_diag(k) end [us]: {'W':>5} {'Qpub':>7} {'bulk':>7} {'res':>7} | {'S':>6} {'U':>6} {'pres':>6} {'next':>6} | last to arrive"
 lines.append(hdr)
 last_count = {}
 for k in steps:
@@ -112,7 +115,7 @@ for k in steps:
     def rel(v):
         return f"{v - pe:7.1f}" if v is not None else "      -"
 
-    lines.append(f"{k:3d} {pe - potrf_start[k]:6.1f} | {'':47s} {potrf_pub.get(k, pe) - pe:5.1f} {rel(qpub)} {rel(bulk)} {rel(res)} | {rel(S)[1:]} {rel(U)[1:]} {nxt - pe:6.1f} | {last}")
+    lines.append(f"{k:3d} {pe - potrf_start[k]:6.1f} | {'':47s} {potrf_pub.get(k, pe) - pe:5.1f} {rel(qpub)} {rel(bulk)} {rel(res)} | {rel(S)[1:]} {rel(U)[1:]} {rel(potrf_res.get(k + 1))[1:]} {nxt - pe:6.1f} | {last}")
 
 dur = np.array([potrf_end[k] - potrf_start[k] for k in sorted(potrf_end)])
 gap = np.array([potrf_start[k + 1] - potrf_end[k] for k in steps])
@@ -124,6 +127,26 @@ out = [f"# critical path of the chain, N={n} d={d} M={m}, one fit+predict step (
        f"# step: {us(rec[-1, 1]):.1f} us from the first to the last logged kernel start; potrf_diag mean {dur.mean():.1f} us; "
        f"gap mean {gap.mean():.1f} us (k >= 10: {gap[10:].mean():.1f}, max {gap[10:].max():.1f})",
        "# last-arriving dependency, count over steps: " + ", ".join(f"{k}: {v}" for k, v in sorted(last_count.items()))] + lines
+# the bulk stream: is it the chain that waits for it, or the other way round?
+bulks = sorted((g for g in gemms if g["role"] == "bulk" and g["end"]), key=lambda g: g["start"])
+panels = sorted((g for g in gemms if g["role"] == "panel" and g["end"] and g["M"] > nb), key=lambda g: g["start"])
+out.append("")
+out.append("# bulk stream T: each launch, the idle time of the stream in front of it, and what it started behind: the previous bulk")
+out.append("# launch (T is the bottleneck there) or the panel it applies (the chain is).  busy = sum of launches / span.")
+out.append(f"{'cf':>3} {'tiles(M,N,K)':>18} {'start':>8} {'ran':>6} {'idle':>6} {'after panel end':>16}")
+prev_end = None
+busy = 0.0
+for g in bulks:
+    cf = (rows_total - g["M"]) // nb
+    # the panel whose rows start at block row cf - 2 - near... the latest panel that ended before this launch started
+    pe_ = [p_["end"] for p_ in panels if p_["end"] <= g["start"] + 0.5]
+    after_panel = g["start"] - max(pe_) if pe_ else float("nan")
+    idle = g["start"] - prev_end if prev_end is not None else 0.0
+    out.append(f"{cf:3d} {g['M']:6d},{g['N']:5d},{g['K']:4d} {g['start']:8.1f} {g['end'] - g['start']:6.1f} {idle:6.1f} {after_panel:16.1f}")
+    busy += g["end"] - g["start"]
+    prev_end = g["end"]
+if bulks:
+    out.append(f"# T busy {busy:.1f} us of {bulks[-1]['end'] - bulks[0]['start']:.1f} us between its first start and last end")
 out.append("gap by step:   " + " ".join(f"{g:.0f}" for g in gap))
 out.append("potrf by step: " + " ".join(f"{g:.0f}" for g in dur))
 text = "\n".join(out)
