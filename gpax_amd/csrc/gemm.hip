@@ -33,6 +33,10 @@ struct GemmArgs {
   int a_upper_tri;   // A[m][k] == 0 for k < m (rows of an upper-triangular factor): K below the tile's first row is dead
   // map_S < 0: 1-D row-major enumeration of the lower trapezoid's tiles (row_off == col_off), map_ntj tile columns
   int map_S; int64_t map_ntj;
+  // first_col > 0 (bulk instantiation, 1-D map): the tiles of the first `first_col` tile columns are enumerated FIRST and
+  // publish themselves (write-through stores + one count into `signal`): the consumers of a bulk update's first block column
+  // -- the panel stream's next column update, the chain's band kernel -- need not wait for the whole launch to end
+  int first_col; int64_t map_nti;
   // batched hyper-parameter draws: blockIdx.z = draw, per-draw strides (0: shared)
   int64_t sA, sB, sC, s_flag, s_info;
   // block-cyclic row distribution (distributed factorisation): local row m is global row
@@ -139,20 +143,42 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   GEMM_TL(ROLE == 1 ? 8 : 4, g.M, g.N * 1000000 + g.K);
   batch_offset(g);
   int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  bool first_part = false;   // bulk instantiation: this tile lies in the first block column and publishes itself
   if (g.map_S < 0) {
     // 1-D row-major enumeration of the lower trapezoid's tiles (row_off == col_off): no empty workgroups, and the
     // round-robin deal of consecutive workgroup ids over the 8 XCDs stays balanced whatever the grid width (with
     // the 2-D grid and a width that is a multiple of 8 tiles, XCD x owns the tile columns = x mod 8 and XCD 0
     // gets 25 % more of the triangle than XCD 7: tools/gemm_shape, 33 vs 42 TFLOP/s at 4096 vs 3968 rows)
-    const int64_t id = blockIdx.x, ntj = g.map_ntj, ntri = ntj * (ntj + 1) / 2;
-    int64_t ti, tj;
-    if (id < ntri) {
-      ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
-      while (ti * (ti + 1) / 2 > id) --ti;
-      while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
-      tj = id - ti * (ti + 1) / 2;
-    } else {
-      ti = ntj + (id - ntri) / ntj; tj = (id - ntri) % ntj;
+    int64_t id = blockIdx.x, ntj = g.map_ntj, shift = 0;
+    int64_t ti = 0, tj = 0;
+    bool mapped = false;
+    if (ROLE == 0 && g.first_col > 0) {
+      const int64_t fc = g.first_col, tri1 = fc * (fc + 1) / 2, n1 = fc * g.map_nti - fc * (fc - 1) / 2;
+      if (id < n1) {   // row-major over the first fc tile columns: row r holds min(r + 1, fc) tiles
+        if (id < tri1) {
+          ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+          while (ti * (ti + 1) / 2 > id) --ti;
+          while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+          tj = id - ti * (ti + 1) / 2;
+        } else {
+          ti = fc + (id - tri1) / fc; tj = (id - tri1) % fc;
+        }
+        mapped = true; first_part = true;
+      } else {   // the rest: the same trapezoid without its first fc tile columns (and rows)
+        id -= n1; ntj -= fc; shift = fc;
+      }
+    }
+    if (!mapped) {
+      const int64_t ntri = ntj * (ntj + 1) / 2;
+      if (id < ntri) {
+        ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > id) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+        tj = id - ti * (ti + 1) / 2;
+      } else {
+        ti = ntj + (id - ntri) / ntj; tj = (id - ntri) % ntj;
+      }
+      ti += shift; tj += shift;
     }
     m0 = ti * BM; n0 = tj * BN;
   } else if (g.lower && (tile_global_row(g, m0) + BM - 1 < g.col_off + n0)) {
@@ -294,8 +320,8 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   // the next step, asleep on `signal` -- the way the one-pass kernel does: write-through stores, each wave drains its own,
   // the barrier collects the four waves, ONE lane adds to the agent-scope counter.  Same arithmetic, same bits; the bulk
   // instantiation (ROLE 0) carries none of this.
-  if constexpr (ROLE == 1 && BM == 64) {
-    if (g.signal && m0 < g.signal_m) {
+  if constexpr (BM == 64 && HASC) {
+    if (g.signal && (ROLE == 1 ? m0 < g.signal_m : first_part)) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -326,7 +352,14 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
       for (int r = 0; r < 4; ++r) {
         const int64_t row = m0 + wm * (BM / 2) + i * 16 + fk + 4 * r;
         // (non-temporal and agent-scope write-through stores were A/B-tested here: no effect on the step time)
+#ifdef GEMM_WT_C
+        // experiment: write-through C stores, so that the L2s never hold megabytes of dirty C tiles that every kernel boundary
+        // and release of the OTHER streams has to write back first
+        __hip_atomic_store(&g.C[row * g.ldc + col], HASC ? fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]) : g.alpha * acc[i][j][r],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         g.C[row * g.ldc + col] = HASC ? fma(g.beta, cin[i][j][r], g.alpha * acc[i][j][r]) : g.alpha * acc[i][j][r];
+#endif
       }
     }
   GEMM_STAMP(14);
@@ -521,6 +554,7 @@ struct BandArgs {
   int64_t ld;
   const unsigned* flagW; const unsigned* flagF; unsigned countF;
   unsigned* flagS; unsigned* flagS2; unsigned* flagU; unsigned* flagD;
+  const unsigned* flagB; unsigned countB;   // the bulk launch that last wrote A_{k+1,k+1}: its first block column published (or nullptr)
   int* info;
   int row2, big;
   int64_t sA, sW, s_mini, s_flag, s_info;
@@ -555,13 +589,14 @@ __global__ __launch_bounds__(256, 2) void chain_band_kernel(BandArgs b) {
     b.W += z * b.sW; b.A1 += z * b.sA; b.A2 += z * b.sA; b.D11 += z * b.sA; b.D21 += z * b.sA;
     if (b.P0) b.P0 += z * b.sP0;
     b.S1 += z * b.s_mini; b.S2 += z * b.s_mini;
-    b.flagW += z * b.s_flag; if (b.flagF) b.flagF += z * b.s_flag;
+    b.flagW += z * b.s_flag; if (b.flagF) b.flagF += z * b.s_flag; if (b.flagB) b.flagB += z * b.s_flag;
     b.flagS += z * b.s_flag; b.flagS2 += z * b.s_flag; b.flagU += z * b.s_flag; b.flagD += z * b.s_flag;
     b.info += z * b.s_info;
   }
   TileOp t;
   if (row == 0) {
     if (b.P0 && n0 <= m0) {
+      onepass_wait(b.flagB, b.countB, nullptr, 0u, b.info);
       BAND_TL(3, 1);
       t.A = b.P0; t.B = b.P0; t.C = b.D11; t.lda = b.ldp; t.ldb = b.ldp; t.ldc = b.ld; t.alpha = -1.0; t.beta = 1.0; t.b_lower_tri = 0;
       onepass_tile<K, false>(t, m0, n0, As, Bs, false);
@@ -601,7 +636,7 @@ static void fill_args(GemmArgs& g, const GemmLaunch& L) {
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   g.a_upper_tri = L.a_upper_tri;
-  g.map_S = 0; g.map_ntj = 0;
+  g.map_S = 0; g.map_ntj = 0; g.first_col = 0; g.map_nti = 0;
   g.sA = L.sA; g.sB = L.sB; g.sC = L.sC; g.s_flag = L.s_flag; g.s_info = L.s_info;
   g.signal = L.signal; g.signal_m = L.signal_m; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
   g.wait_flag2 = L.wait_flag2; g.wait_count2 = L.wait_count2; g.wait_m = L.wait_m;
@@ -618,7 +653,7 @@ int launch_chain_band(gpx_handle* h, hipStream_t s, const BandLaunch& L) {
   BandArgs b;
   b.W = L.W; b.A1 = L.A1; b.A2 = L.row2 ? L.A2 : L.A1; b.D11 = L.D11; b.D21 = L.row2 ? L.D21 : L.D11;
   b.P0 = L.P0; b.ldp = L.ldp; b.sP0 = L.sP0; b.S1 = L.S1; b.S2 = L.S2; b.ld = L.ld;
-  b.flagW = L.flagW; b.flagF = L.flagF; b.countF = L.countF; b.flagS = L.flagS; b.flagS2 = L.flagS2; b.flagU = L.flagU; b.flagD = L.flagD;
+  b.flagW = L.flagW; b.flagF = L.flagF; b.countF = L.countF; b.flagS = L.flagS; b.flagS2 = L.flagS2; b.flagU = L.flagU; b.flagD = L.flagD; b.flagB = L.flagB; b.countB = L.countB;
   b.info = L.info; b.row2 = L.row2; b.big = L.big;
   b.sA = L.sA; b.sW = L.sW; b.s_mini = L.s_mini; b.s_flag = L.s_flag; b.s_info = L.s_info;
 #ifdef GPX_TIMELINE
@@ -650,7 +685,9 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
 #endif
   // hand-overs inside a launch: the one-pass kernel (publish and wait), or the 64x64 look-ahead instantiation (publish its
   // first `signal_m` rows only)
-  const bool big_signal = !L.small_tile && L.role == 1 && L.beta != 0.0 && L.signal && L.signal_m > 0 && L.signal_m % 64 == 0 && !L.wait_flag;
+  const bool big_signal = !L.small_tile && L.beta != 0.0 && L.signal && !L.wait_flag &&
+                          ((L.role == 1 && L.signal_m > 0 && L.signal_m % 64 == 0) ||
+                           (L.role == 0 && L.first_col > 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && L.N / 64 > L.first_col));
   if ((L.signal || L.wait_flag) && !(L.small_tile && (L.K == 128 || L.K == 64)) && !big_signal) {
     gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel and the 64x64 look-ahead kernel only");
     return GPX_ERR_ARG;
@@ -665,7 +702,8 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   // round-robin deal of consecutive workgroup ids over the 8 XCDs stays balanced whatever the grid width)
   if (!L.small_tile && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N) {
     const int64_t nti = L.M / 64, ntj = L.N / 64;
-    g.map_S = -1; g.map_ntj = ntj;
+    g.map_S = -1; g.map_ntj = ntj; g.map_nti = nti;
+    if (L.first_col > 0 && L.role == 0 && L.beta != 0.0 && L.signal && ntj > L.first_col) g.first_col = L.first_col;
     const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
     const dim3 tg((unsigned)ntiles, 1u, (unsigned)L.batch);
     if (L.beta != 0.0 && L.role == 1) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true, 1>), tg, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);

@@ -94,6 +94,7 @@ struct GemmLaunch {
   // agent-scope add to this counter) for a consumer that is already resident (potrf_diag's resident start)
   unsigned* signal = nullptr;
   int64_t signal_m = 0;   // > 0: only the tiles whose first row is below signal_m publish and count (the rest store plainly)
+  int first_col = 0;      // bulk launch (role 0, 1-D tile map): enumerate the first `first_col` tile columns first; they publish and count into `signal`
   // one-pass path: the kernel is launched early and sleeps until *wait_flag >= wait_count (a producer that is
   // still running publishes its output with write-through stores and then raises the flag)
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;
@@ -122,6 +123,7 @@ struct BandLaunch {
   unsigned* flagS = nullptr; unsigned* flagS2 = nullptr;    // tiles of S1 / S2 published
   unsigned* flagU = nullptr;                                // tiles of A_{k+1,k+1} published (potrf_diag(k+1) polls)
   unsigned* flagD = nullptr;                                // tiles of A_{k+2,k+1} published (the panel stream's panel of step k+1 polls)
+  const unsigned* flagB = nullptr; unsigned countB = 0;     // phase 0: first block column of the bulk launch that last wrote A_{k+1,k+1}
   int* info = nullptr;
   int row2 = 0, big = 0;   // big: row 2's update in the summation order of the 64x64 look-ahead kernel
   hipEvent_t stop_event = nullptr;
@@ -129,7 +131,7 @@ struct BandLaunch {
   int64_t sA = 0, sW = 0, s_mini = 0, s_flag = 0, s_info = 0;
 };
 int launch_chain_band(gpx_handle* h, hipStream_t s, const BandLaunch& L);
-#define GPX_N_FLAG_ARRAYS 6   // flagsU, flagsW, flagsS, flagsF, flagsS2, flagsD: nblk words each, per draw
+#define GPX_N_FLAG_ARRAYS 7   // flagsU, flagsW, flagsS, flagsF, flagsS2, flagsD, flagsB: nblk words each, per draw
 
 // Diagonal block: A (nb x nb at lda) -> L (lower, written at ldl) and W = inv(L) (dense nb x nb)
 struct PotrfLaunch {
@@ -283,14 +285,16 @@ struct gpx_handle {
   int nb = 128;
   bool nb_auto = true;   // no explicit "nb" option: 64 for n <= 64 (potrf_diag<64> runs 12 us, <128> 29 us), else 128
   int lookahead = 1;     // 0: everything on one stream; 1: the split-panel schedule from split_min_blocks block columns on
-  int resident = 3;      // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
+  int resident = 2;      // split-panel schedule: 0 = every hand-over of the chain is a kernel boundary; 1 = potrf_diag starts resident
                          // (sleeps on the tile counter of A -= S S^T); 2 = also S = A W_k^T starts resident (sleeps on potrf_diag's flag);
-                         // 3 = also ONE potrf_diag workgroup per draw for the whole factorisation (it keeps its CU)
+                         // 3 = also ONE potrf_diag workgroup per draw for the whole factorisation (it keeps its CU; measured, not the
+                         // default: the relay kernels it needs on the panel stream cost what the CU wait did)
   int pair_min = 28;     // pair the bulk updates (K = 2 nb) while more than this many block columns remain; 0 = never
   int quad_min = 40;     // ... and four at a time (K = 4 nb) while more than this many remain; 0 = never
   int split_min_blocks = 3;   // the split-panel (multi-stream) schedule runs from this many block columns; below, one stream
   int la_rows = 3072;    // look-ahead column updates use 64x64 tiles while at least this many rows remain below; 0 = never
   int batch_group = 4;   // batches of >= 4 draws: bulk updates grouped g panels at a time throughout (0: the single-draw thresholds)
+  int bulk_first_col = 1;  // ungrouped bulk launches enumerate and publish their first block column first (schedule.hip)
   int chain_overlap = 0;   // potrf_diag(k) is launched WITHOUT the queue barrier (it may start while potrf_diag(k-1) runs: its order is
                            // carried by the device flags) in the last `chain_overlap` block columns; 0 = never
   int debug_force_timeout = 0;   // test hook: the next factorisation's first resident wait gives up at once (info = -7)

@@ -191,7 +191,7 @@ struct SplitSchedule {
   hipStream_t P, P2, Q, T;
   bool resident, chain2, fuse_band, kinv, attach, use_dib, persistent, lp_flag = false;
   unsigned n_signal;
-  unsigned *flagsU, *flagsW, *flagsS, *flagsF, *flagsS2, *flagsD;
+  unsigned *flagsU, *flagsW, *flagsS, *flagsF, *flagsS2, *flagsD, *flagsB;
   // "diagonal block in the band kernel" (fused band kernel, ungrouped steps).  The column update of step j used to
   // cover column j+2 from its diagonal block down, behind the wait for the bulk launch that last wrote that column, and
   // the band kernel of step j+1 waited for all of it -- on alternate block columns of the chain-bound middle of the
@@ -207,6 +207,7 @@ struct SplitSchedule {
   std::vector<int64_t> band_t;
   std::vector<hipEvent_t> tev;        // hand-over event of the bulk launch of step k (set when it is launched)
   std::vector<char> t_pending;
+  std::vector<unsigned> t_pub;        // > 0: the bulk launch of step k publishes its first block column (flagsB[k] counts to this)
   int64_t pair_min, quad_min;
   int64_t last_t = -1;        // last group end (panels <= last_t are in every column >= last_t+3: by Q's near block and T's bulk launch)
   int64_t group_end = -1;     // the step at which T acts next
@@ -252,6 +253,7 @@ struct SplitSchedule {
     flagsS = h->d_flags + 2 * nblk;   // [k]: tiles of S published (fused band kernel: its second phase waits)
     flagsF = h->d_flags + 3 * nblk;   // [k]: first block rows of the panel stream's column updates of step k published (row 2 of the band kernel of step k+1 waits)
     flagsS2 = h->d_flags + 4 * nblk;  // [k]: tiles of S2 published (row 2 of the fused band kernel)
+    flagsB = h->d_flags + 6 * nblk;   // [k]: tiles of the first block column of the bulk launch of step k published (Q's next column update, the band kernel)
     flagsD = h->d_flags + 5 * nblk;   // [k]: tiles of A_{k+2,k+1} published by row 2 (the first block row of Q's panel k+1 waits)
     // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
     // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
@@ -267,7 +269,7 @@ struct SplitSchedule {
     }
     t_from = nblk;
     dib.assign((size_t)nblk + 2, 0); band_t.assign((size_t)nblk + 2, -1); far_flag.assign((size_t)nblk + 2, 0);
-    tev.assign((size_t)nblk, nullptr); t_pending.assign((size_t)nblk, 0);
+    tev.assign((size_t)nblk, nullptr); t_pending.assign((size_t)nblk, 0); t_pub.assign((size_t)nblk, 0u);
     if (resident && h->debug_force_timeout) { force_timeout_at = 1; h->debug_force_timeout = 0; }
     if (resident && !h->flags_clean) {
       if (M.batch == 1) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_flags, 0, (size_t)(GPX_N_FLAG_ARRAYS * nblk) * sizeof(unsigned), P));
@@ -390,7 +392,11 @@ struct SplitSchedule {
       near_step = -1;   // (otherwise ev_far[k-1], k-1 > near_step, was recorded behind it)
     }
     const bool phase0 = dib[(size_t)k] != 0;   // block (k+1,k+1) -= L_{k+1,k-1} L_{k+1,k-1}^T (panel k-1), see dib[] above
-    if (phase0 && band_t[(size_t)k] >= 0) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)band_t[(size_t)k]], 0));   // the bulk launch that last wrote the block
+    // the bulk launch that last wrote the block: its completion event -- or, where that launch publishes its first block
+    // column (which holds the block), the band kernel's phase 0 waits for the counter itself
+    const int64_t bt = phase0 ? band_t[(size_t)k] : -1;
+    const bool bulk_by_flag = bt >= 0 && fuse_band && t_pub[(size_t)bt] > 0;
+    if (bt >= 0 && !bulk_by_flag) GPX_HIP_CHECK(h, hipStreamWaitEvent(PB, tev[(size_t)bt], 0));
     if (fuse_band) {   // the whole band (phase 0, S1, the diagonal block, and row 2) in one launch
       BandLaunch b;
       b.nb = (int)nb; b.W = c.W(k); b.ld = c.ld;
@@ -406,6 +412,7 @@ struct SplitSchedule {
       }
       b.flagW = flagsW + k; b.flagS = flagsS + k; b.flagS2 = flagsS2 + k; b.flagU = flagsU + k; b.flagD = flagsD + k; b.info = h->d_info;
       if (b.row2 && far_by_flag) { b.flagF = flagsF + (k - 1); b.countF = far_count(k - 1); }
+      if (bulk_by_flag) { b.flagB = flagsB + bt; b.countB = t_pub[(size_t)bt]; }
       b.batch = c.M.batch; b.sA = c.M.sA; b.sW = c.M.sW; b.s_mini = h->s_mini; b.s_flag = h->s_flags; b.s_info = c.s_info;
       prof_begin(h, PB, GPX_STAGE_LOOKAHEAD, B * ((phase0 ? 3.0 : 2.0) + (b.row2 ? 2.0 : 0.0)) * (double)nb * nb * nb, B * 8.0 * 6.0 * nb * nb);
       GPX_RET(launch_chain_band(h, PB, b));
@@ -563,7 +570,15 @@ struct SplitSchedule {
         GPX_RET(col_update(k, k + 1, 1, k, 1, true, rf ? 1 : 0, rf));
         if (!far_attached) GPX_HIP_CHECK(h, hipEventRecord(h->ev_far[(size_t)k], Q));
         far_attached = true;   // recorded (or attached) already: not again behind the second column
-        if (col2_in_bulk) GPX_RET(q_wait_for_bulk());
+        // column k+2 is the first block column of the most recent bulk launch: wait for THAT (a one-wave relay kernel on
+        // the launch's counter) where the launch publishes it, not for the launch to end -- round 2's event wait here closed
+        // a loop  bulk(k-1) ends -> this update -> panel(k+1) -> bulk(k+1)  that was longer than a bulk launch (T idled
+        // ~10 us in front of every launch of the bulk-bound phase, profiles/r03_critical_path_persist.txt)
+        if (col2_in_bulk) {
+          if (t_idx >= 0 && t_pub[(size_t)t_idx] > 0 && t_from == k + 2) {
+            if (t_idx != q_waited_t) GPX_RET(launch_chain_relay(h, Q, flagsB + t_idx, t_pub[(size_t)t_idx], h->d_info, c.M.batch, h->s_flags, c.s_info));
+          } else GPX_RET(q_wait_for_bulk());
+        }
         GPX_RET(col_update(k, k + 2, 1, k, 1, false, 1, rf));
       } else if (ncb > 1 && npan2 > 1) {
         // grouped phases: column k+1 (whose last bulk update Q waited for a step ago) needs no bulk update to finish,
@@ -604,6 +619,13 @@ struct SplitSchedule {
       const int64_t kfirst = last_t + 1, npan = k - last_t;
       const int64_t cf = k + 3 + near_cols, br = cf * nb, bm = rows - br, nc = nbulk * nb;
       GemmLaunch t = c.update(br, bm, cf, nbulk, kfirst, npan, false);
+      // ungrouped steps of the fused chain: the first block column (the only part of this launch the next step's column
+      // update and band kernel need) is enumerated first and publishes itself
+      if (fuse_band && !kinv && npan == 1 && near_cols == 0 && nbulk >= 2 && nb % 64 == 0 && h->bulk_first_col) {
+        const int64_t fc = nb / 64, nti = bm / 64;
+        t.first_col = (int)fc; t.signal = flagsB + k;
+        t_pub[(size_t)k] = (unsigned)(fc * nti - fc * (fc - 1) / 2);
+      }
       const double entries = trapezoid_entries(bm, nc);
       // profiled: the kernel's own dispatch timestamps (what rocprofv3 reports), the hand-over event recorded behind it
       const bool timed = prof_pair(h, GPX_STAGE_TRAILING, B * 2.0 * entries * t.K, B * 8.0 * (2.0 * entries + (double)(bm + nc) * t.K),
@@ -664,14 +686,35 @@ struct SplitSchedule {
 
 }  // namespace
 
+#ifdef GPX_TIMELINE
+#include <chrono>
+// diagnostic build only: host time (us since the loop began) at which step k's launches were enqueued: [2k] chain, [2k+1] side
+double g_tl_host[1024];
+int g_tl_host_n = 0;
+extern "C" int gpx_timeline_host(double* out, int n) {
+  const int m = n < g_tl_host_n ? n : g_tl_host_n;
+  for (int i = 0; i < m; ++i) out[i] = g_tl_host[i];
+  return m;
+}
+#define TL_HOST(i) do { if ((i) < 1024) { g_tl_host[(i)] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tl_t0).count(); g_tl_host_n = (i) + 1; } } while (0)
+#else
+#define TL_HOST(i) do { } while (0)
+#endif
+
 int factor_loop(gpx_handle* h, const Mats& M, int64_t tri_base) {
   const int64_t nblk = M.npad / M.nb;
   if (h->lookahead == 0 || nblk < h->split_min_blocks) return factor_loop_single(h, make_ctx(h, M, tri_base));
   SplitSchedule s;
+#ifdef GPX_TIMELINE
+  const auto tl_t0 = std::chrono::steady_clock::now();
+#endif
   GPX_RET(s.init(h, M, tri_base));
   for (int64_t k = 0; k < nblk; ++k) {
+    TL_HOST(2 * k);
     GPX_RET(s.chain(k));
+    TL_HOST(2 * k + 1);
     GPX_RET(s.side(k));
   }
+  TL_HOST(2 * nblk);
   return s.finish();
 }

@@ -225,7 +225,7 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *   "lookahead"    0 = everything on one stream, 1 = the split-panel schedule on four streams (1)
  *   "resident"     split-panel schedule: 0 = the chain's kernels hand over at kernel boundaries, 1 = potrf_diag starts
  *                  resident and sleeps on a device flag, 2 = so does the band kernel S = A W_k^T, A -= S S^T, 3 = and ONE
- *                  potrf_diag workgroup per draw walks the whole diagonal, keeping its CU (3; falls back to 0 under
+ *                  potrf_diag workgroup per draw walks the whole diagonal, keeping its CU (2; falls back to 0 under
  *                  hardware-counter collection, under per-launch bracketing, and for good once a wait timed out)
  *   "pair_min" / "quad_min"  group the bulk updates two / four panels at a time while more than this many block
  *                  columns remain; 0 = never (28 / 40)

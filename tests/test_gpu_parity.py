@@ -177,8 +177,8 @@ def test_split_schedule_is_deterministic(core):
 @pytest.mark.parametrize("resident", [3, 2, 1, 0])
 @pytest.mark.parametrize("n,m,grouped", [(200, 250, False), (1100, 90, False), (1333, 77, True)])
 def test_handover_modes_are_bit_identical(core, resident, n, m, grouped):
-    """The in-kernel hand-overs of the split-panel schedule (resident 3, the default: ONE potrf_diag workgroup walks the
-    whole diagonal and the fused band kernel sleeps on device flags; 2: one potrf_diag launch per block, started resident;
+    """The in-kernel hand-overs of the split-panel schedule (resident 3: ONE potrf_diag workgroup walks the whole diagonal
+    and the fused band kernel sleeps on device flags; 2, the default: one potrf_diag launch per block, started resident;
     1: potrf_diag only; 0: every hand-over is a kernel boundary, which is also the mode a handle falls back to after a
     timed-out wait) only move WHEN a kernel runs: all four return the very same bits -- and the oracle's numbers.
     (The reference bits are taken with resident = 0.)"""
@@ -204,7 +204,7 @@ def test_handover_modes_are_bit_identical(core, resident, n, m, grouped):
             assert np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
     finally:
         core.set_option("split_min_blocks", 3)
-        core.set_option("resident", 3)
+        core.set_option("resident", 2)
         core.set_option("nb", 0)
         core.set_option("pair_min", 28)
         core.set_option("quad_min", 40)
@@ -241,10 +241,10 @@ def test_grouped_bulk_updates_match_the_oracle(core, pair_min, quad_min):
     assert np.abs(mean - mean_ref).max() <= TOL_POST and np.abs(var - var_ref).max() <= TOL_POST
 
 
-@pytest.mark.parametrize("option,value", [("resident", 0), ("resident", 1), ("resident", 2)])
+@pytest.mark.parametrize("option,value", [("resident", 0), ("resident", 1), ("resident", 3)])
 def test_optional_schedule_features_match_the_default(core, option, value):
-    """The in-kernel hand-overs of the chain (default resident = 3: one potrf_diag workgroup for the whole diagonal, the band
-    kernel sleeping on flags raised by its producers) against kernel-boundary hand-overs (0) and the half-way modes (1, 2):
+    """The in-kernel hand-overs of the chain (default resident = 2: potrf_diag and the band kernel start resident and sleep on
+    flags raised by their producers) against kernel-boundary hand-overs (0), the half-way mode (1) and the one-workgroup diagonal (3):
     same bits as the default schedule, for the factor as well as the fused step."""
     import gpax_amd
     from oracle import gp_oracle as orc
@@ -261,7 +261,7 @@ def test_optional_schedule_features_match_the_default(core, option, value):
         info1, logp1, mean1, var1 = core.fit_predict(prm, y - 1.0, np.ones(90), 0.0)
         assert info0 == 0 and info1 == 0
         assert np.array_equal(l0, l1) and logp0 == logp1 and np.array_equal(mean0, mean1) and np.array_equal(var0, var1)
-    core.set_option(option, 3)
+    core.set_option(option, 2)
     logp_ref, mean_ref, var_ref = orc.fit_predict(orc.RBF, x, y, xn, p)
     assert abs(logp1 - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
 

@@ -210,7 +210,7 @@ def test_forced_handover_timeout_retries_with_kernel_boundaries():
     ref_core.close()
     for mode in ("sync", "async", "grad"):
         c = gpax_amd.Core(0)
-        assert c.get_option("resident") == 3
+        assert c.get_option("resident") == 2
         c.set_train(x)
         c.set_test(xn)
         c.set_option("debug_force_timeout", 1)

@@ -147,6 +147,19 @@ for g in bulks:
     prev_end = g["end"]
 if bulks:
     out.append(f"# T busy {busy:.1f} us of {bulks[-1]['end'] - bulks[0]['start']:.1f} us between its first start and last end")
+# host enqueue times (diagnostic build): when were step k's launches queued, and how long did each call take?
+if hasattr(lib, "gpx_timeline_host"):
+    hb = (C.c_double * 1024)()
+    nh = lib.gpx_timeline_host(hb, 1024)
+    ht = np.array(hb[:nh])
+    if nh >= 3:
+        ch = ht[1::2][: nblk] - ht[0::2][: nblk]          # chain(k) call
+        sd = ht[2::2][: nblk] - ht[1::2][: nblk]          # side(k) call
+        out.append("")
+        out.append(f"# host: the factor loop enqueued {nblk} steps in {ht[-1]:.0f} us (chain(k) calls {ch.sum():.0f} us, side(k) calls {sd.sum():.0f} us)")
+        out.append("host chain(k) us: " + " ".join(f"{v:.0f}" for v in ch))
+        out.append("host side(k) us:  " + " ".join(f"{v:.0f}" for v in sd))
+        out.append("host t(chain k):  " + " ".join(f"{v:.0f}" for v in ht[0::2][: nblk]))
 out.append("gap by step:   " + " ".join(f"{g:.0f}" for g in gap))
 out.append("potrf by step: " + " ".join(f"{g:.0f}" for g in dur))
 text = "\n".join(out)

@@ -33,21 +33,23 @@ buf = (C.c_ulonglong * (4 * 16000))()
 lib.gpx_timeline_read.restype = C.c_longlong
 cnt = lib.gpx_timeline_read(buf, C.c_longlong(16000))
 rec = np.frombuffer(buf, dtype=np.uint64)[: 4 * cnt].reshape(-1, 4).astype(np.int64)
-ends_buf = (C.c_ulonglong * 8192)()
+ends_buf = (C.c_ulonglong * 16384)()
 lib.gpx_timeline_read_ends.restype = C.c_longlong
-lib.gpx_timeline_read_ends(ends_buf, C.c_longlong(8192))
+lib.gpx_timeline_read_ends(ends_buf, C.c_longlong(16384))
 ends = np.frombuffer(ends_buf, dtype=np.uint64).astype(np.int64)
 rec = rec[np.argsort(rec[:, 1])]
 t0 = rec[0, 1]
 us = (rec[:, 1] - t0) / 100.0
 nb = 128
-names = {1: "potrf start", 2: "potrf end", 5: "potrf resident"}
+names = {1: "potrf start", 2: "potrf end", 5: "potrf resident", 7: "potrf pub"}
 rows = []
 for (kind0, tstart, a, b), t in zip(rec, us):
     kind, tl_id = kind0 & 255, (kind0 >> 8) - 1
     dur = f"  ran {(ends[tl_id] - tstart) / 100.0:6.1f} us" if (tl_id >= 0 and ends[tl_id] > 0) else ""
+    if tl_id >= 0 and ends[8192 + tl_id] > 0:
+        dur += f"  pub at {(ends[8192 + tl_id] - t0) / 100.0:8.1f}"
     b = int(b)
-    if kind in (1, 2, 5):
+    if kind in (1, 2, 5, 7):
         rows.append((t, names[kind], f"k={a // nb}"))
     elif kind == 3:
         N_, beta = b // 1000000, b % 1000000
@@ -56,8 +58,8 @@ for (kind0, tstart, a, b), t in zip(rec, us):
     elif kind == 6:
         N_, beta = b // 1000000, b % 1000000
         rows.append((t, "  resident:", ("mini-update" if beta else "mini-panel") + f" M={a} N={N_}"))
-    elif kind == 4:
-        rows.append((t, "T bulk", f"M={a} N={b // 1000000} K={b % 1000000}{dur}"))
+    elif kind in (4, 8):
+        rows.append((t, "T bulk" if kind == 4 else "Q col64", f"M={a} N={b // 1000000} K={b % 1000000}{dur}"))
 print(f"{cnt} records; step spans {us[-1]:.1f} us from first to last logged start")
 lo, hi = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (12, 15)
 show = False
