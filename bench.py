@@ -465,6 +465,36 @@ def main():
                                 "step_tflops": B * (nb_ ** 3 / 3 + nb_ * nb_ * (m + 1)) / (ms * 1e-3) * 1e-12,
                                 "ok": bool((info_b == 0).all() and np.isfinite(logp_b).all() and (var_b > 0).all())})
             out["batched"] = batched
+
+            # ---- batched gradient calls (gpx_lml_grad_batch): the leapfrog steps of B NUTS chains in lock-step, against B
+            # single gpx_lml_grad calls (what ExactGP.fit(num_chains=B, chain_method="sequential") issues)
+            grad_batched = []
+            core.set_test(np.zeros((0, d)))
+            for nb_, B in ((256, 4), (1024, 4), (1024, 8), (4096, 4)):
+                xs, ys, _ = synthetic_problem(nb_, d, m, seed=0)
+                core.set_train(xs)
+                rngb = np.random.default_rng(2)
+                plist = [gpax_amd.make_params(kind, float(np.exp(0.3 * rngb.standard_normal())), np.exp(0.3 * rngb.standard_normal(d)),
+                                              None, np.array([k_noise]), 1e-6, True) for _ in range(B)]
+                rb = np.stack([ys - 1.0] * B)
+                for _ in range(2):
+                    core.lml_grad_batch(plist, rb)
+                    core.lml_grad(plist[0], rb[0])
+                reps = 10 if nb_ <= 1024 else 4
+                t6 = time.perf_counter()
+                for _ in range(reps):
+                    info_g, logp_g, grads_g, _ = core.lml_grad_batch(plist, rb)
+                ms_b = (time.perf_counter() - t6) / reps * 1e3
+                t7 = time.perf_counter()
+                for _ in range(reps):
+                    for i in range(B):
+                        core.lml_grad(plist[i], rb[i])
+                ms_s = (time.perf_counter() - t7) / reps * 1e3
+                grad_batched.append({"B": B, "n": nb_, "ms_per_batch": ms_b, "ms_single_calls": ms_s, "speedup": ms_s / ms_b,
+                                     "grad_calls_per_s": B / (ms_b * 1e-3),
+                                     "ok": bool((info_g == 0).all() and np.isfinite(logp_g).all())})
+            out["grad_batched"] = grad_batched
+            core.set_test(x_new)
             load(x, y - 1.0, x_new, np.ones(m))   # back to the headline problem for the CPU comparison below
 
         if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only

@@ -72,6 +72,7 @@ SIGNATURES = {
     "gpx_fit_factor": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), _dp, _dp]),
     "gpx_log_marginal": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "gpx_lml_grad": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), _dp, _dp, _dp, _dp]),
+    "gpx_lml_grad_batch": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(KernelParams), _dp, _dp, _dp, _dp, C.POINTER(C.c_int32)]),
     "gpx_posterior": (C.c_int, [C.c_void_p, _dp, C.c_double, _dp, _dp, _dp]),
     "gpx_prior_cov": (C.c_int, [C.c_void_p, C.POINTER(KernelParams), C.c_double, _dp]),
     "gpx_mvn_sample": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64, _dp, C.c_int64, _dp]),
@@ -316,6 +317,33 @@ class Core:
             grads["k_period"] = g[1 + p.n_length : 1 + p.n_length + n_per]
         grads["k_noise"] = g[-1:]
         return info, logp.value, grads, alpha
+
+    def lml_grad_batch(self, param_list, y_minus_m, want_alpha=True):
+        """``gpx_lml_grad_batch``: B log-marginal likelihoods and gradients in one schedule.  ``param_list``: B
+        ``make_params`` results of one form; ``y_minus_m`` (B, n).  Returns ``(info (B,), logp (B,), grads, alpha (B, n))``
+        with ``grads`` a list of B dicts keyed like ``lml_grad``'s."""
+        B = len(param_list)
+        arr, _keep = make_params_batch(param_list)
+        r = _arr(y_minus_m).reshape(B, -1)
+        if r.shape[1] != self.n:
+            raise ValueError("y_minus_m must be (B, n)")
+        p0 = param_list[0][0]
+        n_per = p0.n_period if p0.kind == PERIODIC else 0
+        ng = 2 + p0.n_length + n_per
+        g = np.empty((B, ng))
+        logp = np.empty(B)
+        alpha = np.empty((B, self.n)) if want_alpha else None
+        info = np.zeros(B, dtype=np.int32)
+        self._check(self._lib.gpx_lml_grad_batch(self._h, B, arr, _ptr(r), _ptr(logp), _ptr(g), _ptr(alpha),
+                                                 info.ctypes.data_as(C.POINTER(C.c_int32))), "gpx_lml_grad_batch")
+        grads = []
+        for b in range(B):
+            gb = {"k_scale": g[b, 0:1], "k_length": g[b, 1 : 1 + p0.n_length]}
+            if n_per:
+                gb["k_period"] = g[b, 1 + p0.n_length : 1 + p0.n_length + n_per]
+            gb["k_noise"] = g[b, -1:]
+            grads.append(gb)
+        return info, logp, grads, alpha
 
     def posterior(self, m_new=None, new_noise=0.0, want_mean=True, want_var=True, want_cov=False):
         mn = _arr(m_new).reshape(-1) if m_new is not None else None

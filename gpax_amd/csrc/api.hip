@@ -797,6 +797,34 @@ extern "C" int gpx_log_marginal(gpx_handle* h, const double* y_minus_m, double* 
 
 // ----------------------------------------------- log-marginal likelihood with its gradient
 
+// grad_out layout: [k_scale | k_length (n_length) | k_period (n_period, periodic only) | k_noise], from the reduction's sums
+static int grads_from_sums(const gpx_kernel_params* p, const double* sums, int d, int per_dim, int info, double* grad_out) {
+  const int DCH = grad_chunk_dims(), NPVv = grad_partials_per_chunk();
+  const double sc = p->k_scale;
+  int o = 0;
+  grad_out[o++] = 0.5 * sums[0];
+  auto dim_sum = [&](int k, int which) { return sums[(size_t)(k / DCH) * NPVv + 4 + which * DCH + k % DCH]; };
+  if (p->n_length == 1) {
+    double acc = 0.0;
+    if (per_dim) for (int k = 0; k < d; ++k) acc += dim_sum(k, 0); else acc = sums[2];
+    grad_out[o++] = 0.5 * sc * acc / p->k_length[0];
+  } else {
+    for (int k = 0; k < d; ++k) grad_out[o++] = 0.5 * sc * dim_sum(k, 0) / p->k_length[k];
+  }
+  if (p->kind == GPX_PERIODIC) {
+    if (p->n_period == 1) {
+      double acc = 0.0;   // the sums carry 1/l_d^2 already
+      if (per_dim) for (int k = 0; k < d; ++k) acc += dim_sum(k, 1); else acc = sums[3];
+      grad_out[o++] = 0.5 * sc * acc / (2.0 * p->k_period[0]);
+    } else {
+      for (int k = 0; k < d; ++k) grad_out[o++] = 0.5 * sc * dim_sum(k, 1) / (2.0 * p->k_period[k]);
+    }
+  }
+  grad_out[o++] = (p->apply_noise && p->n_noise == 1) ? 0.5 * sums[1] : 0.0;
+  if (info != 0) for (int i = 0; i < o; ++i) grad_out[i] = NAN;
+  return o;
+}
+
 // One bordered factorisation of [K ; r ; I] -> [L ; z^T ; U = L^-T] (the identity rows are activated
 // block by block, factor_loop's tri_base), then alpha = U z, K^-1 = U U^T (lower tiles, dead-K skipped)
 // and ONE pass over K^-1 that recomputes dK/dtheta from x (grad.hip).  ~N^3 flops in total against
@@ -928,31 +956,7 @@ static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double
   factor_commit(h, p, 0, true);
   if (logp) *logp = -0.5 * scal[1] - scal[0] - 0.5 * (double)n * log(2.0 * M_PI);
 
-  if (grad_out) {
-    // layout: [k_scale | k_length (n_length) | k_period (n_period, periodic only) | k_noise]
-    const double sc = p->k_scale;
-    int o = 0;
-    grad_out[o++] = 0.5 * sums[0];
-    auto dim_sum = [&](int k, int which) { return sums[(size_t)(k / DCH) * NPVv + 4 + which * DCH + k % DCH]; };
-    if (p->n_length == 1) {
-      double acc = 0.0;
-      if (per_dim) for (int k = 0; k < d; ++k) acc += dim_sum(k, 0); else acc = sums[2];
-      grad_out[o++] = 0.5 * sc * acc / p->k_length[0];
-    } else {
-      for (int k = 0; k < d; ++k) grad_out[o++] = 0.5 * sc * dim_sum(k, 0) / p->k_length[k];
-    }
-    if (p->kind == GPX_PERIODIC) {
-      if (p->n_period == 1) {
-        double acc = 0.0;   // the sums carry 1/l_d^2 already
-        if (per_dim) for (int k = 0; k < d; ++k) acc += dim_sum(k, 1); else acc = sums[3];
-        grad_out[o++] = 0.5 * sc * acc / (2.0 * p->k_period[0]);
-      } else {
-        for (int k = 0; k < d; ++k) grad_out[o++] = 0.5 * sc * dim_sum(k, 1) / (2.0 * p->k_period[k]);
-      }
-    }
-    grad_out[o++] = (p->apply_noise && p->n_noise == 1) ? 0.5 * sums[1] : 0.0;
-    if (info != 0) for (int i = 0; i < o; ++i) grad_out[i] = NAN;
-  }
+  if (grad_out) grads_from_sums(p, sums, d, per_dim, info, grad_out);
   return info;
 }
 
@@ -960,6 +964,131 @@ extern "C" int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const dou
                             double* grad_out, double* alpha_out) {
   if (!h) return GPX_ERR_ARG;
   return with_retry([&] { return lml_grad_once(h, p, y_minus_m, logp, grad_out, alpha_out); });
+}
+
+static void batch_invalidate(gpx_handle* h);
+
+// B gradient evaluations in ONE schedule: what jax.vmap / chain_method="vectorized" make of the NUTS potential in the reference
+// (gpax/gp.py:507-509, 517-525).  Every kernel of lml_grad_once is launched once with the draw index in its grid: per draw the
+// bordered matrix [K ; r ; I], the factorisation with K^-1 accumulated on the bulk stream, the epilogue (+ alpha) and the
+// reduction.  Same arithmetic per draw as the single-draw call with the same grouping thresholds.
+static int lml_grad_batch_once(gpx_handle* h, int batch, const gpx_kernel_params* params, const double* y_minus_m, double* logp,
+                               double* grad_out, double* alpha_out, int32_t* info_out) {
+  GPX_HIP_CHECK(h, hipSetDevice(h->device));
+  const gpx_kernel_params* p = params;
+  const int64_t n = h->n, nb = h->nb; const int d = h->d;
+  const int64_t npad = round_up(n, nb), ld = npad;
+  const int64_t RZ = 64;
+  const int64_t epad = RZ + round_up(n, 64);
+  const int64_t rows = npad + epad, n64 = round_up(n, 64);
+  hipStream_t s = h->s_main;
+  for (int b = 1; b < batch; ++b)
+    if (params[b].n_length != p->n_length || params[b].n_period != p->n_period) {
+      gpx_set_error(h, "gpx_lml_grad_batch: the draws must share the form of k_length / k_period"); return GPX_ERR_ARG;
+    }
+
+  h->have_factor = false; h->have_z = false; h->m_resident = 0;
+  h->batch = batch; h->s_mat = rows * ld; h->s_w = npad * nb; h->s_z = npad; h->s_r = n; h->s_mnew = 0; h->s_kinv = n64 * npad;
+  GPX_RET(ensure(h, &h->d_A, &h->a_cap, h->s_mat * batch));
+  GPX_RET(ensure(h, &h->d_L, &h->l_cap, h->s_mat * batch));
+  GPX_RET(ensure(h, &h->d_W, &h->w_cap, h->s_w * batch));
+  GPX_RET(ensure(h, &h->d_z, &h->z_cap, h->s_z * batch));
+  GPX_RET(ensure(h, &h->d_r, &h->r_cap, n * batch));
+  GPX_RET(ensure(h, &h->d_kinv, &h->kinv_cap, h->s_kinv * batch));
+  const int per_dim = (p->n_length > 1 || (p->kind == GPX_PERIODIC && p->n_period > 1)) ? 1 : 0;
+  const int DCH = grad_chunk_dims(), NPVv = grad_partials_per_chunk();
+  const int nchunk = per_dim ? (d + DCH - 1) / DCH : 1;
+  const int64_t tail = npad + (int64_t)nchunk * NPVv;
+  GPX_RET(ensure_out(h, tail, batch));
+  GPX_RET(ensure_events(h, (size_t)(npad / nb), (int)nb, batch));
+  h->npad = npad; h->epad = epad; h->ld = ld;
+  const int64_t s_info = 2 * h->s_out;
+
+  const double* noise_dev;
+  GPX_RET(upload_params_batch(h, s, params, batch, n, d, &noise_dev, nullptr));
+  GPX_HIP_CHECK(h, hipMemcpyAsync(h->d_r, y_minus_m, (size_t)(n * batch) * sizeof(double), hipMemcpyHostToDevice, s));
+
+  // ---- [K ; r ; I] per draw in d_A
+  GramLaunch g;
+  g.kind = p->kind; g.d = d; g.k_scale = 0.0; g.hyp = h->d_hyp; g.dev_scalars = h->d_hyp + 2 * d;
+  g.x1 = h->d_x; g.x2 = h->d_x; g.n1 = n; g.n2 = n; g.out = h->d_A; g.ld = ld;
+  g.lower_only = 1; g.diag_rule = p->apply_noise ? 1 : 0;
+  g.noise = noise_dev; g.noise_scalar = 0.0; g.jitter = 0.0;
+  g.zero_info = h->d_info;
+  g.batch = batch; g.s_out = h->s_mat; g.s_hyp = h->s_hyp; g.s_noise = h->s_noise; g.s_info = s_info; g.s_flags = h->s_flags;
+  {
+    const double T = (double)((n + 63) / 64);
+    const double entries = T * (T + 1) / 2.0 * 4096.0;
+    prof_begin(h, s, GPX_STAGE_GRAM, batch * gram_flops_per_entry(p->kind, d) * entries, batch * (8.0 * entries + 16.0 * n * d));
+    GPX_RET(launch_gram(h, s, g));
+    prof_end(h, s);
+  }
+  GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows, batch, h->s_mat));
+  double* Ab = h->d_A + npad * ld;                       // border of draw 0
+  GPX_RET(launch_border_rows(h, s, h->d_A, ld, npad, n, npad, h->d_r, npad + 1, npad + RZ, nullptr, batch, h->s_mat, n));
+  GPX_RET(launch_fill_rect(h, s, Ab + RZ * ld, ld, 0, n, 0, n, 1.0, batch, h->s_mat));          // identity rows
+  GPX_RET(launch_fill_rect(h, s, Ab + RZ * ld, ld, n, epad - RZ, 0, n, 0.0, batch, h->s_mat));
+  GPX_RET(launch_fill_rect(h, s, h->d_L + npad * ld, ld, 0, epad, 0, npad, 0.0, batch, h->s_mat));   // the dead lower-left of U reads as zeros
+
+  const double* zrow = h->d_L + npad * ld;
+  const double* U = h->d_L + (npad + RZ) * ld;
+  const bool split = h->lookahead != 0 && npad / nb >= h->split_min_blocks;
+  if (split) { h->kinv_U = U; h->kinv_rows = n64; }
+  int frc = factor_loop(h, primary_mats(h, rows), npad + RZ);
+  h->kinv_U = nullptr; h->kinv_rows = 0;
+  if (frc != GPX_OK) { batch_invalidate(h); return frc; }
+
+  EpilogueLaunch e;
+  e.L = h->d_L; e.ld = ld; e.n = n; e.z = zrow; e.vt = nullptr; e.vt_ld = 0; e.m = 0; e.m_new = nullptr;
+  e.prior_diag = 0.0; e.scal = h->d_scal; e.mean = nullptr; e.var = nullptr;
+  e.z_copy = h->d_z; e.npad = npad;
+  double* alpha = h->d_mean;
+  e.gemv_U = U; e.gemv_alpha = alpha; e.gemv_ncols = npad;
+  e.batch = batch; e.s_mat = h->s_mat; e.s_out = h->s_out; e.s_zcopy = h->s_z;
+  GPX_RET(launch_epilogue(h, s, e));
+
+  if (!split) {
+    GemmLaunch u;
+    u.A = U; u.lda = ld; u.B = U; u.ldb = ld; u.C = h->d_kinv; u.ldc = npad;
+    u.M = n64; u.N = n64; u.K = npad; u.alpha = 1.0; u.beta = 0.0;
+    u.lower = 1; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = 0; u.a_upper_tri = 1;
+    u.batch = batch; u.sA = h->s_mat; u.sB = h->s_mat; u.sC = h->s_kinv;
+    GPX_RET(launch_gemm_nt(h, s, u));
+  }
+
+  const int64_t T = (n + 63) / 64, ntiles = T * (T + 1) / 2;
+  const int nwg = ntiles <= 3 ? 1 : (int)std::min<int64_t>(ntiles, 1024);
+  GPX_RET(ensure(h, &h->d_gpart, &h->gpart_cap, (int64_t)nchunk * nwg * NPVv * batch));
+  double* sums_dev = h->d_mean + npad;
+  GPX_RET(launch_grad_reduce(h, s, p->kind, h->d_x, h->d_hyp, h->d_kinv, npad, alpha, n, d, per_dim, nwg, h->d_gpart,
+                             sums_dev, batch, h->s_hyp, h->s_kinv, h->s_out));
+
+  const double* blk = nullptr;
+  const int rc = fetch_block(h, tail, &blk, batch);
+  const int64_t so = h->s_out;
+  batch_invalidate(h);
+  GPX_RET(rc);
+  const int ng = 2 + p->n_length + (p->kind == GPX_PERIODIC ? p->n_period : 0);
+  int worst = 0;
+  for (int b = 0; b < batch; ++b) {
+    const double* q = blk + so * b;
+    const int info = reinterpret_cast<const int*>(q + 8)[0];
+    GPX_RET(check_handover(h, info));
+    if (info_out) info_out[b] = info;
+    if (info > worst) worst = info;
+    if (logp) logp[b] = -0.5 * q[1] - q[0] - 0.5 * (double)n * log(2.0 * M_PI);
+    if (alpha_out) memcpy(alpha_out + n * b, q + GPX_OUT_HEAD, (size_t)n * sizeof(double));
+    if (grad_out) grads_from_sums(params + b, q + GPX_OUT_HEAD + npad, d, per_dim, info, grad_out + (int64_t)ng * b);
+  }
+  return worst;
+}
+
+extern "C" int gpx_lml_grad_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* params, const double* y_minus_m,
+                                  double* logp, double* grad_out, double* alpha_out, int32_t* info_out) {
+  if (!h) return GPX_ERR_ARG;
+  if (batch < 1 || batch > 4096 || !params || !y_minus_m) { gpx_set_error(h, "gpx_lml_grad_batch: bad argument"); return GPX_ERR_ARG; }
+  if (h->n <= 0 || !h->d_x) { gpx_set_error(h, "gpx_lml_grad_batch: call gpx_set_train first"); return GPX_ERR_STATE; }
+  return with_retry([&] { return lml_grad_batch_once(h, batch, params, y_minus_m, logp, grad_out, alpha_out, info_out); });
 }
 
 static void cached_params(gpx_handle* h, gpx_kernel_params* q) {

@@ -221,7 +221,7 @@ int grad_partials_per_chunk(void);
 int grad_chunk_dims(void);
 int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* hyp, const double* kinv,
                        int64_t ldk, const double* alpha, int64_t n, int d, int per_dim, int nwg, double* part,
-                       double* sums);
+                       double* sums, int batch = 1, int64_t s_hyp = 0, int64_t s_kinv = 0, int64_t s_out = 0);
 int launch_utri_gemv(gpx_handle* h, hipStream_t s, const double* U, int64_t ld, const double* z, double* alpha,
                      int64_t n, int64_t ncols);
 
@@ -338,6 +338,7 @@ struct gpx_handle {
   // set by gpx_lml_grad around its factorisation: accumulate K^-1 += U_{:,k} U_{:,k}^T on the bulk stream as the
   // panels complete (U = the identity border rows of d_L) instead of one U U^T product after the last panel
   const double* kinv_U = nullptr; int64_t kinv_rows = 0;
+  int64_t s_kinv = 0;   // per-draw stride (doubles) of d_kinv in a batched gradient call
   double* d_gpart = nullptr; int64_t gpart_cap = 0;
   // secondary factor buffers (Cholesky of the posterior covariance for MVN sampling)
   double* d_A2 = nullptr; int64_t a2_cap = 0;

@@ -31,6 +31,8 @@ struct GradArgs {
   double* part;           // [gridDim.y][gridDim.x][NPV]
   int64_t n, ldk, ntiles;
   int d, per_dim;
+  // batched hyper-parameter draws (blockIdx.z = draw): per-draw strides in doubles; x is shared
+  int64_t s_hyp, s_kinv, s_alpha, s_part;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -50,6 +52,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs g) {
   const int cj = tid & 31, ri = tid >> 5;
   const int lrow = tid >> 2, lk = (tid & 3) * 4;
   const int chunk0 = blockIdx.y * DC;   // the dimension chunk whose per-dimension sums this workgroup owns
+  if (blockIdx.z) {
+    const int64_t z = blockIdx.z;
+    g.hyp += z * g.s_hyp; g.kinv += z * g.s_kinv; g.alpha += z * g.s_alpha; g.part += z * g.s_part;
+  }
 
   double accS = 0.0, accN = 0.0, accLi = 0.0, accPi = 0.0;
   double accL[DC], accP[DC];
@@ -206,9 +212,10 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs g) {
 
 // sums[chunk][v] = sum over workgroups of part[chunk][wg][v], fixed association (strided partial sums per
 // thread, then a binary tree): bitwise reproducible for a given launch geometry
-__global__ __launch_bounds__(256) void grad_final_kernel(const double* part, double* sums, int nwg) {
+__global__ __launch_bounds__(256) void grad_final_kernel(const double* part, double* sums, int nwg, int64_t s_part, int64_t s_sums) {
   __shared__ double sh[256];
   const int chunk = blockIdx.y, v = blockIdx.x, tid = threadIdx.x;
+  part += (int64_t)blockIdx.z * s_part; sums += (int64_t)blockIdx.z * s_sums;
   double s = 0.0;
   for (int w = tid; w < nwg; w += 256) s += part[((int64_t)chunk * nwg + w) * NPV + v];
   sh[tid] = s;
@@ -226,10 +233,11 @@ int grad_chunk_dims(void) { return DC; }
 // part: device scratch of nchunk * nwg * NPV doubles; sums: device, nchunk * NPV doubles
 int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* hyp, const double* kinv,
                        int64_t ldk, const double* alpha, int64_t n, int d, int per_dim, int nwg, double* part,
-                       double* sums) {
+                       double* sums, int batch, int64_t s_hyp, int64_t s_kinv, int64_t s_out) {
   GradArgs g;
   g.x = x; g.hyp = hyp; g.kinv = kinv; g.alpha = alpha; g.part = part;
   g.n = n; g.ldk = ldk; g.d = d; g.per_dim = per_dim;
+  if (batch < 1) { gpx_set_error(h, "grad_reduce: batch < 1"); return GPX_ERR_ARG; }
   const int64_t T = (n + GT - 1) / GT;
   g.ntiles = T * (T + 1) / 2;
   const int nchunk = per_dim ? (d + DC - 1) / DC : 1;
@@ -241,7 +249,9 @@ int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, 
   // applies (the caller passes nwg = 1 for up to three tiles) a launch costs more than the three tiles
   const bool direct = nwg == 1;
   if (direct) g.part = sums;
-  dim3 grid((unsigned)nwg, (unsigned)nchunk);
+  // draw b: hyp + b s_hyp, kinv + b s_kinv, alpha and sums inside its result block (+ b s_out), part + b nchunk nwg NPV
+  g.s_hyp = s_hyp; g.s_kinv = s_kinv; g.s_alpha = s_out; g.s_part = direct ? s_out : (int64_t)nchunk * nwg * NPV;
+  dim3 grid((unsigned)nwg, (unsigned)nchunk, (unsigned)batch);
   switch (kind) {
     case GPX_RBF: hipLaunchKernelGGL((grad_reduce_kernel<GPX_RBF>), grid, dim3(256), 0, s, g); break;
     case GPX_MATERN52: hipLaunchKernelGGL((grad_reduce_kernel<GPX_MATERN52>), grid, dim3(256), 0, s, g); break;
@@ -250,7 +260,8 @@ int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, 
   }
   GPX_HIP_CHECK(h, hipGetLastError());
   if (direct) return GPX_OK;
-  hipLaunchKernelGGL(grad_final_kernel, dim3(NPV, (unsigned)nchunk), dim3(256), 0, s, part, sums, nwg);
+  hipLaunchKernelGGL(grad_final_kernel, dim3(NPV, (unsigned)nchunk, (unsigned)batch), dim3(256), 0, s, part, sums, nwg,
+                     (int64_t)nchunk * nwg * NPV, s_out);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

@@ -282,7 +282,7 @@ struct SplitSchedule {
     if (resident) GPX_HIP_CHECK(h, hipStreamWaitEvent(P2, h->ev_join, 0));
     // gradient path: K^-1 is accumulated on T while the chain runs (see kinv_update below); T is idle until the
     // first panel is complete, so clearing the accumulator there costs nothing
-    if (kinv) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_kinv, 0, (size_t)(h->kinv_rows * c.npad) * sizeof(double), T));
+    if (kinv) GPX_HIP_CHECK(h, hipMemsetAsync(h->d_kinv, 0, (size_t)(M.batch > 1 ? h->s_kinv * M.batch : h->kinv_rows * c.npad) * sizeof(double), T));
     plan_band();
     return GPX_OK;
   }
@@ -504,8 +504,9 @@ struct SplitSchedule {
     t.C = h->d_kinv; t.ldc = c.npad;
     t.M = msq; t.N = msq; t.K = npan * nb; t.alpha = 1.0; t.beta = 1.0;
     t.lower = 1; t.row_off = 0; t.col_off = 0; t.b_lower_tri = 0; t.small_tile = 0;
+    t.batch = c.M.batch; t.sA = c.M.sA; t.sB = c.M.sA; t.sC = h->s_kinv; t.s_flag = h->s_flags; t.s_info = c.s_info;   // U lives in the factor matrices
     const double entries = (double)msq * (msq + 1) / 2.0;
-    prof_begin(h, T, GPX_STAGE_TRAILING, 2.0 * entries * t.K, 8.0 * (2.0 * entries + 2.0 * (double)msq * t.K));
+    prof_begin(h, T, GPX_STAGE_TRAILING, B * 2.0 * entries * t.K, B * 8.0 * (2.0 * entries + 2.0 * (double)msq * t.K));
     int rc = launch_gemm_nt(h, T, t);
     prof_end(h, T);
     return rc;

@@ -247,10 +247,15 @@ class GaussianProcess:
         if info != 0:
             return float("nan"), {}
         out = {k: np.asarray(v, dtype=np.float64) for k, v in grads.items() if k in params}
-        # d logp / d theta_m = alpha . dm/dtheta_m.  A Mean that implements `_mean_grad(x, **params)` (name -> dm/dtheta,
-        # shape (N,) or (plate, N)) is differentiated exactly -- what jax.grad gives the reference under NUTS
-        # (gpax/gp.py:145-151; jnp.piecewise / jnp.where have zero derivative in the break point almost everywhere);
-        # without the hook: central differences on the O(N) host function.
+        out.update(self._mean_param_grads(x, m_params, alpha))
+        return logp, out
+
+    def _mean_param_grads(self, x, m_params, alpha):
+        """d logp / d theta_m = alpha . dm/dtheta_m.  A Mean that implements ``_mean_grad(x, **params)`` (name -> dm/dtheta,
+        shape (N,) or (plate, N)) is differentiated exactly -- what jax.grad gives the reference under NUTS
+        (gpax/gp.py:145-151; jnp.piecewise / jnp.where have zero derivative in the break point almost everywhere);
+        without the hook: central differences on the O(N) host function."""
+        out = {}
         exact = self.mean._mean_grad(x, **m_params) if m_params else None
         for name, val in m_params.items():
             val = np.atleast_1d(np.asarray(val, dtype=np.float64))
@@ -267,7 +272,30 @@ class GaussianProcess:
                 dm = (self.mean(x, **{**m_params, name: up}) - self.mean(x, **{**m_params, name: dn})) / (2 * h)
                 g[i] = float(alpha @ np.broadcast_to(dm, alpha.shape))
             out[name] = g.reshape(val.shape)
-        return logp, out
+        return out
+
+    def log_marginal_and_grad_batch(self, params_list):
+        """``log_marginal_and_grad`` for B parameter sets in ONE schedule on the GPU (``gpx_lml_grad_batch``): what the
+        reference gets from running its NUTS chains vectorised (``chain_method``, gpax/gp.py:507-509, 517-525).  Returns a
+        list of ``(logp, grads)``; a draw's numbers are those of the single call, bit for bit."""
+        if len(params_list) == 1:
+            return [self.log_marginal_and_grad(params_list[0])]
+        core, x = self._make_train_resident()
+        core._gp_factor = None
+        y = self.y_transformed
+        split = [self._split(p) for p in params_list]
+        plist = [self._kernel_struct(k_params, k_noise, k_jitter, x.shape[0]) for _, k_params, k_noise, k_jitter in split]
+        r = np.stack([y - self.mean(x, **m_params) for m_params, _, _, _ in split])
+        info, logp, grads, alpha = core.lml_grad_batch(plist, r)
+        res = []
+        for b, (m_params, _, _, _) in enumerate(split):
+            if info[b] != 0:
+                res.append((float("nan"), {}))
+                continue
+            out = {k: np.asarray(v, dtype=np.float64) for k, v in grads[b].items() if k in params_list[b]}
+            out.update(self._mean_param_grads(x, m_params, alpha[b]))
+            res.append((float(logp[b]), out))
+        return res
 
     def _gp_prior(self, x=None, y=None, params=None, rng=None):
         """The GP model of gpax/gp.py:133-151.  Without NumPyro there are no sample sites: with
@@ -573,9 +601,9 @@ class _ParamSpace:
     def init_to_median(self):
         return np.concatenate([np.atleast_1d(d.to_unconstrained(np.full(pl, d.median))) for _, d, pl in self.items])
 
-    def value_and_grad(self, gp, u):
-        """Log joint density in unconstrained space (priors + log|Jacobian| + log-marginal) and its
-        gradient: the potential NumPyro differentiates for NUTS / SVI, one ``gpx_lml_grad`` call."""
+    def _prior_terms(self, u):
+        """Host half of the potential at ``u``: the constrained parameters, d x / d u, the gradient of the log-prior +
+        log|Jacobian| and its value (``None`` where the point is outside the support or overflows: a rejected -inf)."""
         params, g_prior, dx, o = dict(self.constants), np.zeros(self.dim), np.zeros(self.dim), 0
         log_prior = 0.0
         with np.errstate(all="ignore"):   # far-out trial points of the step-size search overflow to a rejected -inf
@@ -594,12 +622,15 @@ class _ParamSpace:
                 dx[o : o + plate], g_prior[o : o + plate] = dxdu, gterm
                 o += plate
         if not math.isfinite(log_prior):
-            return -np.inf, np.zeros(self.dim)
+            return None
         for v in params.values():   # (ndarray methods: the np.all / np.isfinite wrappers cost 20 us per call here)
             a = np.asarray(v, dtype=np.float64)
             if not (np.isfinite(a).all() and (np.abs(a) < 1e150).all()):
-                return -np.inf, np.zeros(self.dim)
-        logp, grads = gp.log_marginal_and_grad(params)
+                return None
+        return params, g_prior, dx, log_prior
+
+    def _finish(self, terms, logp, grads):
+        _, g_prior, dx, log_prior = terms
         val = logp + log_prior
         if not np.isfinite(val):
             return -np.inf, np.zeros(self.dim)
@@ -609,6 +640,27 @@ class _ParamSpace:
             g[o : o + plate] += dx[o : o + plate] * (gv if gv.size == plate else np.broadcast_to(gv, (plate,)))
             o += plate
         return val, g
+
+    def value_and_grad(self, gp, u):
+        """Log joint density in unconstrained space (priors + log|Jacobian| + log-marginal) and its
+        gradient: the potential NumPyro differentiates for NUTS / SVI, one ``gpx_lml_grad`` call."""
+        terms = self._prior_terms(u)
+        if terms is None:
+            return -np.inf, np.zeros(self.dim)
+        logp, grads = gp.log_marginal_and_grad(terms[0])
+        return self._finish(terms, logp, grads)
+
+    def value_and_grad_batch(self, gp, us):
+        """``value_and_grad`` at several points with ONE batched GPU call (``gpx_lml_grad_batch``) for those inside the
+        support: the potentials of chains stepping in lock-step."""
+        terms = [self._prior_terms(u) for u in us]
+        live = [i for i, t in enumerate(terms) if t is not None]
+        res = [(-np.inf, np.zeros(self.dim))] * len(us)
+        if live:
+            outs = gp.log_marginal_and_grad_batch([terms[i][0] for i in live])
+            for i, (logp, grads) in zip(live, outs):
+                res[i] = self._finish(terms[i], logp, grads)
+        return res
 
     def constrain(self, u):
         out, o = {}, 0
@@ -640,9 +692,17 @@ class ExactGP(GaussianProcess):
         space = _ParamSpace(self)
         kw = dict(self.mcmc_run_kwargs)
         draws, infos = {name: [] for name, _, _ in space.items}, []
-        for _ in range(self.num_chains):   # chain_method "sequential" (gpax/gp.py:509)
-            u0 = space.init_to_median()
-            d, info = mcmc.sample(lambda u: space.value_and_grad(self, u), u0, self.num_warmup, self.hp_samples, rng, **kw)
+        # one independent child stream per chain: a chain's draws do not depend on how the chains are scheduled
+        rngs = [rng] if self.num_chains == 1 else [np.random.default_rng(sq) for sq in np.random.SeedSequence(int(rng.integers(0, 2**63 - 1))).spawn(self.num_chains)]
+        if self.num_chains > 1 and self.chain_method != "sequential":
+            # the reference's "vectorized" / "parallel" chain methods (gpax/gp.py:507-509): the chains step in LOCK-STEP,
+            # every leapfrog step of all of them is one gpx_lml_grad_batch call
+            results = mcmc.sample_lockstep(lambda us: space.value_and_grad_batch(self, us), [space.init_to_median() for _ in rngs],
+                                           self.num_warmup, self.hp_samples, rngs, **kw)
+        else:   # chain_method "sequential" (gpax/gp.py:509, the reference default)
+            results = [mcmc.sample(lambda u: space.value_and_grad(self, u), space.init_to_median(), self.num_warmup, self.hp_samples, r, **kw)
+                       for r in rngs]
+        for d, info in results:
             for row in d:
                 for name, v in space.constrain(row).items():
                     draws[name].append(v)

@@ -281,3 +281,77 @@ def sample(value_and_grad, u0, num_warmup, num_samples, rng, algorithm="nuts", t
     info = dict(step_size=eps, inverse_mass=minv, mean_accept=float(np.mean(accs)) if accs else float("nan"),
                 divergences=n_div, num_grad_evals=n_grad[0], num_leapfrog_total=n_steps_total)
     return draws, info
+
+
+class _LockStep:
+    """Gathers one gradient request per running chain, evaluates them with ONE batched call and hands the results back:
+    the chains (one thread each, plain ``sample`` inside) advance in lock-step, leapfrog step by leapfrog step."""
+
+    def __init__(self, n_chains, batch_fn):
+        import threading
+
+        self.cv = threading.Condition()
+        self.batch_fn, self.active = batch_fn, n_chains
+        self.pending, self.results, self.error = {}, {}, None
+        self.calls, self.points = 0, 0
+
+    def _flush(self):
+        ids = sorted(self.pending)
+        try:
+            outs = self.batch_fn([self.pending[i] for i in ids])
+            self.calls += 1
+            self.points += len(ids)
+            self.results.update(zip(ids, outs))
+        except BaseException as e:   # every waiting chain must wake up and fail
+            self.error = e
+        self.pending.clear()
+        self.cv.notify_all()
+
+    def call(self, cid, u):
+        with self.cv:
+            self.pending[cid] = u
+            if len(self.pending) == self.active:
+                self._flush()
+            while cid not in self.results and self.error is None:
+                self.cv.wait()
+            if self.error is not None:
+                raise RuntimeError("a batched gradient call failed") from self.error
+            return self.results.pop(cid)
+
+    def done(self):
+        with self.cv:
+            self.active -= 1
+            if self.pending and len(self.pending) == self.active:
+                self._flush()
+
+
+def sample_lockstep(value_and_grad_batch, u0s, num_warmup, num_samples, rngs, **kw):
+    """``sample`` for several chains whose gradient evaluations are batched: ``value_and_grad_batch(list of u)`` returns a
+    list of ``(log_density, gradient)``.  Each chain runs the ordinary sampler on its own random stream, so its draws are
+    those of a sequential run with the same stream.  Returns ``[(draws, info), ...]`` in chain order; every ``info``
+    carries ``batched_calls`` / ``batched_points`` (GPU calls issued and points evaluated by them, all chains)."""
+    import threading
+
+    n = len(u0s)
+    gate = _LockStep(n, value_and_grad_batch)
+    out, errs = [None] * n, [None] * n
+
+    def run(cid):
+        try:
+            out[cid] = sample(lambda u: gate.call(cid, u), u0s[cid], num_warmup, num_samples, rngs[cid], **kw)
+        except BaseException as e:
+            errs[cid] = e
+        finally:
+            gate.done()
+
+    threads = [threading.Thread(target=run, args=(i,), name=f"gpx-chain-{i}") for i in range(n)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    for _, info in out:
+        info["batched_calls"], info["batched_points"] = gate.calls, gate.points
+    return out

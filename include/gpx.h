@@ -118,6 +118,15 @@ int gpx_log_marginal(gpx_handle* h, const double* y_minus_m, double* logp, doubl
 int gpx_lml_grad(gpx_handle* h, const gpx_kernel_params* p, const double* y_minus_m, double* logp,
                  double* grad_out, double* alpha_out);
 
+/* `batch` gradient evaluations in ONE schedule -- the reference's NUTS chains run vectorised (chain_method, gpax/gp.py:507-509,
+ * 517-525) as one jitted program; here every kernel of gpx_lml_grad is launched once with the draw index in its grid.
+ * params[batch] (same kind, apply_noise, form of k_noise / k_length / k_period), y_minus_m (batch, n), logp[batch],
+ * grad_out (batch, ng) with ng = 2 + n_length (+ n_period for the periodic kernel) laid out per draw as in gpx_lml_grad,
+ * alpha_out (batch, n) optional, info_out[batch] optional.  A draw's numbers are those of a gpx_lml_grad call with the same
+ * grouping thresholds, bit for bit.  Leaves no cached factor.  Returns the largest info. */
+int gpx_lml_grad_batch(gpx_handle* h, int32_t batch, const gpx_kernel_params* params, const double* y_minus_m,
+                       double* logp, double* grad_out, double* alpha_out, int32_t* info_out);
+
 /* _get_mean_and_covariance (gpax/gp.py:247-312, Cholesky branch :295-301) at the
  * resident x_new with the cached factor and the y_minus_m of the last
  * gpx_log_marginal:  mean = m_new + k_cross K^-1 r,  cov = k_new - k_cross K^-1 k_cross^T,

@@ -221,3 +221,90 @@ def test_exact_mean_gradient_hook_against_central_differences():
     _, g2 = gp2.log_marginal_and_grad(params)      # central differences of the host mean function
     assert abs(g2["m_beta1"][0] - g["m_beta1"][0]) <= 1e-5 * max(1.0, abs(g["m_beta1"][0]))
     assert abs(g2["m_beta2"][0] - g["m_beta2"][0]) <= 1e-5 * max(1.0, abs(g["m_beta2"][0]))
+
+
+@pytest.mark.parametrize("kind,n,d,ard,b,opts", [
+    (0, 60, 2, True, 3, {}),                      # one block column: the single-stream schedule
+    (1, 300, 3, False, 4, {}),                    # three block columns: split schedule, in-kernel hand-overs (<= 4 draws)
+    (2, 190, 3, True, 2, {}),                     # periodic, ARD length-scales
+    (0, 1024, 8, False, 4, {}),                   # the size the bench's "grad_batched" entry runs
+    (0, 1400, 4, True, 6, {"pair_min": 4, "quad_min": 8}),   # > 4 draws: kernel-boundary hand-overs; grouped K^-1 passes
+])
+def test_batched_gradient_calls_equal_single_calls_and_the_oracle(core, kind, n, d, ard, b, opts):
+    """``gpx_lml_grad_batch``: B gradient evaluations in one schedule (the reference's vectorised NUTS chains,
+    gpax/gp.py:507-509, 517-525).  Per draw: the bits of a single ``gpx_lml_grad`` call, and the oracle's closed form."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, r0, rng = _problem(n, d, seed=n + b)
+    draws = []
+    for _ in range(b):
+        ell = rng.uniform(0.7, 1.5, d) if ard else np.array([float(rng.uniform(0.7, 1.5))])
+        per = (np.array([float(rng.uniform(1.5, 2.5))]) if kind == 2 else None)
+        draws.append((float(rng.uniform(0.8, 1.4)), ell, per, float(rng.uniform(0.01, 0.05))))
+    plist = [gpax_amd.make_params(kind, s, ell, per, np.array([nz]), 1e-6, True) for s, ell, per, nz in draws]
+    r = np.stack([r0 + 0.1 * i for i in range(b)])     # a different prior mean per chain
+    saved = {k: core.get_option(k) for k in opts}
+    try:
+        for k, v in opts.items():
+            core.set_option(k, v)
+        core.set_train(x)
+        info, logp, grads, alpha = core.lml_grad_batch(plist, r)
+        info2, logp2, grads2, alpha2 = core.lml_grad_batch(plist, r)
+        singles = [core.lml_grad(plist[i], r[i]) for i in range(b)]
+    finally:
+        for k, v in saved.items():
+            core.set_option(k, v)
+    assert (info == 0).all() and np.array_equal(logp, logp2) and np.array_equal(alpha, alpha2)
+    for i, (s, ell, per, nz) in enumerate(draws):
+        si, sl, sg, sa = singles[i]
+        assert si == 0 and sl == logp[i] and np.array_equal(sa, alpha[i])
+        assert all(np.array_equal(sg[k], grads[i][k]) and np.array_equal(grads[i][k], grads2[i][k]) for k in sg)
+        if n <= 400 or i == 0:      # the oracle forms an (n, n, d) tensor
+            logp_ref, g_ref, alpha_ref = orc.lml_grad(kind, x, r[i], s, ell, per, nz, 1e-6)
+            assert abs(logp[i] - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+            assert np.abs(alpha[i] - alpha_ref).max() <= TOL_ALPHA_REL * np.abs(alpha_ref).max()
+            scale = max(np.abs(v).max() for v in g_ref.values())
+            for name, ref in g_ref.items():
+                assert np.abs(grads[i][name] - ref).max() <= TOL_GRAD_REL * scale, (name, grads[i][name], ref)
+
+
+def test_batched_gradient_reports_a_bad_draw_and_leaves_the_others_alone(core):
+    import gpax_amd
+
+    x, r0, _ = _problem(300, 2, seed=2)
+    good = np.full(300, 0.01)
+    bad = good.copy()
+    bad[137] = -5.0
+    plist = [gpax_amd.make_params(0, 1.0, 1.0, None, v, 1e-6) for v in (good, bad, good)]
+    core.set_train(x)
+    info, logp, grads, alpha = core.lml_grad_batch(plist, np.stack([r0] * 3))
+    assert list(info) == [0, 138, 0]
+    assert np.isfinite(logp[[0, 2]]).all() and all(np.isnan(v).all() for v in grads[1].values())
+    i0, l0, g0, a0 = core.lml_grad(plist[0], r0)
+    assert l0 == logp[0] == logp[2] and np.array_equal(a0, alpha[2])
+
+
+def test_fit_with_lockstep_chains_equals_sequential_chains():
+    """``ExactGP.fit(num_chains = 3, chain_method = "vectorized")``: the chains' leapfrog steps are batched into
+    ``gpx_lml_grad_batch`` calls; every chain keeps the draws of the sequential run (same random streams, and a batched
+    gradient carries the bits of the single call)."""
+    import gpax_amd
+    from gpax_amd import state
+
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, (160, 2))
+    y = np.sin(3 * x[:, 0]) * np.cos(2 * x[:, 1]) + 0.1 * rng.standard_normal(160)
+    fits = {}
+    for method in ("sequential", "vectorized"):
+        state.set_rng_key(17)
+        gp = gpax_amd.ExactGP(kernel=gpax_amd.RBFKernel(), x=x, y=y, hp_samples=12, num_warmup=25, num_chains=3, chain_method=method)
+        gp.fit()
+        fits[method] = gp
+    a, b = fits["sequential"], fits["vectorized"]
+    assert set(a.mcmc) == set(b.mcmc)
+    for k in a.mcmc:
+        assert a.mcmc[k].shape[0] == 36 and np.array_equal(a.mcmc[k], b.mcmc[k]), k
+    info = b.metadata["mcmc_info"]
+    total = sum(i["num_grad_evals"] for i in info)
+    assert info[0]["batched_calls"] < total and info[0]["batched_points"] == total    # fewer GPU calls than gradient evaluations

@@ -257,3 +257,35 @@ def test_reference_named_helpers_exist():
         acq._analytic_evaluation(None, np.zeros((3, 1)))
     with pytest.raises(ValueError):
         acq._monte_carlo_evaluation(None, np.zeros((3, 1)))
+
+
+def test_lockstep_chains_equal_sequential_chains_on_a_toy_density():
+    """``mcmc.sample_lockstep`` (the chains of ``ExactGP.fit(num_chains > 1, chain_method="vectorized")``: one thread per
+    chain, every round of gradient requests served by ONE batched call) gives each chain the draws of a sequential run on
+    the same random stream, also when chains finish at different times, and fails as a whole when the batched call fails."""
+    import numpy as np
+    import pytest
+
+    from gpax_amd import mcmc
+
+    def vg(u):
+        return float(-0.5 * np.sum(u * u) - 0.1 * np.sum(u**4)), -u - 0.4 * u**3
+
+    sizes = []
+
+    def vgb(us):
+        sizes.append(len(us))
+        return [vg(u) for u in us]
+
+    seq = [mcmc.sample(vg, np.ones(3), 40, 25, np.random.default_rng(s)) for s in (1, 2, 3)]
+    lock = mcmc.sample_lockstep(vgb, [np.ones(3)] * 3, 40, 25, [np.random.default_rng(s) for s in (1, 2, 3)])
+    for (d0, i0), (d1, i1) in zip(seq, lock):
+        assert np.array_equal(d0, d1) and i0["num_grad_evals"] == i1["num_grad_evals"] and i0["step_size"] == i1["step_size"]
+    assert max(sizes) == 3 and min(sizes) >= 1 and sum(sizes) == sum(i["num_grad_evals"] for _, i in lock)
+    assert lock[0][1]["batched_calls"] == len(sizes) < sum(sizes)
+
+    def broken(us):
+        raise ValueError("boom")
+
+    with pytest.raises((RuntimeError, ValueError)):
+        mcmc.sample_lockstep(broken, [np.ones(2)] * 2, 5, 5, [np.random.default_rng(s) for s in (1, 2)])
