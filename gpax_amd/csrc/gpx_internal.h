@@ -15,6 +15,46 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// ------------------------------------------------------------------ exp for the gram epilogues
+// exp(x) for x <= 0 with the constants in SGPRs.  The arithmetic is libdevice's (__ocml_exp_f64: Cody-Waite reduction by
+// ln 2, degree-11 polynomial, v_ldexp_f64) operation for operation -- the results carry the same bits -- but hipcc
+// materialises every 64-bit constant of that routine with two v_mov_b32 in front of a v_fmac_f64 (22 of the routine's ~45
+// VALU instructions; a v_mov_b32 costs a wave the same four issue cycles as a v_fma_f64), and the gram build is bound by
+// exactly that: 8.4 M entries x ~75 VALU instructions at N = 4096.  v_fma_f64 takes the addend from an SGPR pair instead.
+#ifdef __HIPCC__
+__device__ __forceinline__ double gpx_fma_sc(double a, double b, double c_uniform) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+  return d;
+}
+// c_uniform * b + addend (the constant is a multiplicand)
+__device__ __forceinline__ double gpx_fma_cs(double c_uniform, double b, double addend) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(c_uniform), "v"(b), "v"(addend));
+  return d;
+}
+__device__ __forceinline__ double gpx_exp_neg(double x) {
+  double t;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(t) : "s"(0x1.71547652b82fep+0), "v"(x));
+  t = __builtin_rint(t);                                              // n = rint(x log2 e)
+  double r = gpx_fma_cs(-0x1.62e42fefa39efp-1, t, x);                 // r = x - n ln2_hi - n ln2_lo
+  r = gpx_fma_cs(-0x1.abc9e3b39803fp-56, t, r);
+  double p = gpx_fma_sc(r, 0x1.ade156a5dcb37p-26, 0x1.28af3fca7ab0cp-22);
+  p = gpx_fma_sc(r, p, 0x1.71dee623fde64p-19);
+  p = gpx_fma_sc(r, p, 0x1.a01997c89e6b0p-16);
+  p = gpx_fma_sc(r, p, 0x1.a01a014761f6ep-13);
+  p = gpx_fma_sc(r, p, 0x1.6c16c1852b7b0p-10);
+  p = gpx_fma_sc(r, p, 0x1.1111111122322p-7);
+  p = gpx_fma_sc(r, p, 0x1.55555555502a1p-5);
+  p = gpx_fma_sc(r, p, 0x1.5555555555511p-3);
+  p = gpx_fma_sc(r, p, 0x1.000000000000bp-1);
+  p = __builtin_fma(r, p, 1.0);
+  p = __builtin_fma(r, p, 1.0);
+  const double v = __builtin_amdgcn_ldexp(p, (int)t);
+  return x < -1075.0 ? 0.0 : v;
+}
+#endif
+
 // ------------------------------------------------------------------ error plumbing
 #define GPX_HIP_CHECK(h, expr)                                                         \
   do {                                                                                 \

@@ -18,6 +18,8 @@
 // fp64 rate, the inner dimension d is tiny, and the kernel is bound by HBM writes
 // and the fp64 exp, not by the distance arithmetic.
 
+#include <stdlib.h>
+
 #include "gpx_internal.h"
 
 #define GT 64   // output tile edge (64 x 64 entries per 256-thread workgroup)
@@ -131,13 +133,16 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
       const double r2 = acc[r][c];
       double k;
       if (KIND == GPX_RBF) {
-        k = k_scale * exp(-0.5 * r2);                       // kernels.py:123
+        k = k_scale * gpx_exp_neg(-0.5 * r2);               // kernels.py:123
       } else if (KIND == GPX_MATERN52) {
         const double rr = sqrt(r2 + 1e-12);                   // kernels.py:142
         const double s5r = 2.2360679774997896964 * rr;             // 5**0.5 * r
-        k = k_scale * (1.0 + s5r + (5.0 / 3.0) * r2) * exp(-s5r);  // kernels.py:144
+        // 1 + sqrt5 r + 5/3 r2 with the contractions hipcc chose for the plain expression in rounds 1-2, spelled out
+        // (the entries keep their bits whatever else in this function changes)
+        const double poly = __builtin_fma(5.0 / 3.0, r2, __builtin_fma(2.2360679774997896964, rr, 1.0));
+        k = k_scale * poly * gpx_exp_neg(-s5r);                    // kernels.py:144
       } else {
-        k = k_scale * exp(-2.0 * r2);                       // kernels.py:165
+        k = k_scale * gpx_exp_neg(-2.0 * r2);               // kernels.py:165
       }
       const int64_t grow = g.row_gid ? g.row_gid[row] : row;
       if (g.diag_rule && grow == g.col0 + col + c) {
@@ -156,6 +161,13 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     }
   }
 }
+
+// (A slab-shaped variant -- 16 rows x 512 columns per workgroup, one contiguous 1-KiB row segment per wave instruction, the
+// X2 block staged once per 16 rows, the shape that writes a plain 2-GiB stream at 5.7 instead of 4.7 TB/s -- was written in
+// round 3, returned the same bits and ran 1.6-2.3x SLOWER at every size (N = 4096: 46.8 vs 30.0 us, N = 16384: 537 vs 308 us,
+// profiles/r03_gram_slab_vs_tiles.txt): the build is bound by its fp64 VALU work, not by the shape of its stores -- ~75 VALU
+// instructions per entry, 45 of them libdevice's exp -- and 32 entries per thread at four waves per SIMD hide less of it
+// than 16 at eight.  What helped instead is gpx_exp_neg (gpx_internal.h).  Removed.)
 
 int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   if (L.n1 <= 0 || L.n2 <= 0) return GPX_OK;
@@ -249,12 +261,13 @@ __global__ void build_small_kernel(BuildArgs g) {
   }
   const double k_scale = g.dev_scalars[0], noise_scalar = g.dev_scalars[1], jitter = g.dev_scalars[2];
   double kv;
-  if (KIND == GPX_RBF) kv = k_scale * exp(-0.5 * acc);
+  if (KIND == GPX_RBF) kv = k_scale * gpx_exp_neg(-0.5 * acc);
   else if (KIND == GPX_MATERN52) {
     const double rr = sqrt(acc + 1e-12);
     const double s5r = 2.2360679774997896964 * rr;
-    kv = k_scale * (1.0 + s5r + (5.0 / 3.0) * acc) * exp(-s5r);
-  } else kv = k_scale * exp(-2.0 * acc);
+    const double poly = __builtin_fma(5.0 / 3.0, acc, __builtin_fma(2.2360679774997896964, rr, 1.0));   // as in gram_kernel
+    kv = k_scale * poly * gpx_exp_neg(-s5r);
+  } else kv = k_scale * gpx_exp_neg(-2.0 * acc);
   if (diag_row && row == col) kv += ((g.noise ? g.noise[row] : noise_scalar) + jitter);
   *dst = kv;
 }
