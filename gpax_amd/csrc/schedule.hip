@@ -11,6 +11,8 @@
 // blockIdx.z (GEMMs, gram) or blockIdx.x (potrf_diag).  The schedule -- which kernel updates which tile
 // at which step -- does not depend on the batch size, so a draw's bits are those of a single-draw call.
 
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "gpx_internal.h"
