@@ -1,12 +1,15 @@
 #!/bin/bash
 # Regenerates the judged evidence under gpurun_out/refresh/ on the GPU box (copy what is kept into profiles/ as rNN_*):
-#   bench line, rocprofv3 kernel stats of the same command, PMC traffic passes (separate runs), size sweep, step timeline,
-#   batched-draw kernel stats, one-rank distributed kernel stats, peak microbenchmarks, small-N latencies.
-# Usage (from the repo root on the box): bash tools/refresh_profiles.sh
+#   bench line, rocprofv3 kernel stats of the same command, PMC traffic passes (separate runs), size sweep, critical-path table
+#   of the chain (timeline build), same-box A/B against the previous round's library, batched-draw / batched-gradient numbers,
+#   gram-build rates, one-rank distributed kernel stats, peak microbenchmarks, small-N latencies.  Every file is stamped with
+#   the HEAD it was built from (GPX_HEAD, set by the caller: the box has no .git).
+# Usage (from the repo root on the box): GPX_HEAD=<sha> bash tools/refresh_profiles.sh
 set -o pipefail
 R=$PWD
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
+echo "HEAD ${GPX_HEAD:-?}  $(date -u +%FT%TZ)" > $OUT/STAMP
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"; tail -c 200 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
@@ -26,12 +29,19 @@ find $OUT/stats_d -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_dist_o
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/stats $OUT/stats_b $OUT/stats_d
 python3 tools/sweep.py --out $OUT/sweep.json > $OUT/sweep.md 2> $OUT/sweep.err
 echo "sweep done"
+python3 tools/critical_path.py 4096 $OUT/critical_path.txt > /dev/null 2> $OUT/critical_path.err || true
+python3 tools/critical_path.py 2048 $OUT/critical_path_2048.txt > /dev/null 2>> $OUT/critical_path.err || true
+if [ -f tools/ab/libgpx_hip_r2.so ]; then
+  bash tools/ab_round.sh tools/ab/libgpx_hip_r2.so "1024 2048 4096" 6 $OUT/ab_vs_r2.txt > /dev/null 2>&1 || true
+  bash tools/ab_round.sh tools/ab/libgpx_hip_r2.so "8192 16384" 3 $OUT/ab_vs_r2_large.txt > /dev/null 2>&1 || true
+fi
+python3 tools/gradbatch_bench.py > $OUT/grad_batched.txt 2>&1 || true
+for cfg in "4096 8 0" "4096 16 1" "8192 8 0" "16384 8 0" "16384 16 1" "32768 8 0"; do python3 tools/gram_time.py $cfg; done > $OUT/gram.txt 2>&1 || true
 python3 tools/batch_sweep.py 4096 1,2,4,8,16 28:40 > $OUT/batch_sweep_4096.txt 2>&1
 python3 tools/batch_sweep.py 1024 1,4,16,64 28:40 > $OUT/batch_sweep_1024.txt 2>&1
-GPX_LIB_COMPAT=1 python3 tools/timeline2.py 4096 12 15 > $OUT/step_timeline.txt 2>&1 || true
 python3 tools/small_n.py > $OUT/small_n.txt 2>&1 || true
 ./tools/peaks > $OUT/peaks.txt 2>&1 || true
 ./tools/potrf_stamps > $OUT/potrf_diag_stamps.txt 2>&1 || true
-./tools/dpp_probe > $OUT/dpp_probe.txt 2>&1 || true
 python3 tools/fit_bench.py > $OUT/fit_bench.txt 2>&1 || true
+for f in $OUT/*.txt $OUT/*.md; do sed -i "1i # built from HEAD ${GPX_HEAD:-?}" $f; done
 ls -la $OUT
