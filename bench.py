@@ -11,8 +11,8 @@ SURVEY.md section 8(d).
 Multi-GPU (--gpus N, launched by torch.distributed.run, one rank per GPU): the path shards
 over independent hyper-parameter draws (gpax's vmap over hp samples, gpax/gp.py:384-390):
 rank r factorises its own draw on its own GPU, no data-path collective, weak scaling.
-torch.distributed (gloo, CPU tensors) is used only for the barrier and the max-over-ranks clock, and only
-when WORLD_SIZE > 1; torch.cuda is never touched (the library is loaded FIRST so that it binds the ROCm
+The control plane (barrier, max-over-ranks clock, NCCL unique id) is gpax_amd._control: plain TCP sockets around rank 0,
+only when WORLD_SIZE > 1; neither torch.distributed nor torch.cuda is ever imported (the library binds the ROCm
 runtime it was built against and not PyTorch's bundled one -- gpx_runtime_info).
 
 Prints ONE JSON line (rank 0).
@@ -80,11 +80,7 @@ def _committed_traffic(kernel):
 
 
 def _max_over_ranks(dist, value):
-    import torch
-
-    t = torch.tensor([value], dtype=torch.float64)   # CPU tensor over gloo
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return dist.max(value)   # gpax_amd._control.ControlPlane: plain sockets, no second HIP runtime in the process
 
 
 def bench_distributed(args, rank, local_rank, world, dist):
@@ -126,7 +122,7 @@ def bench_distributed(args, rank, local_rank, world, dist):
     step.close()
     if dist:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
 
 
 def dist_leg(args, rank, local_rank, world, dist, out):
@@ -231,12 +227,14 @@ def main():
 
     dist = None
     if world > 1 or args.dist_rehearsal:
-        import torch.distributed as dist_mod   # control plane only (gloo, CPU tensors): barrier + MAX of the clocks
+        # control plane only (barrier, MAX of the clocks, the NCCL unique id): plain sockets around rank 0.  NOT
+        # torch.distributed: importing it maps PyTorch's bundled HIP + HSA runtimes beside the /opt/rocm ones the library
+        # is bound to (checked with /proc/self/maps)
+        from gpax_amd import _control
 
-        dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist = _control.activate(_control.ControlPlane.from_env())
     if os.environ.get("GPX_BENCH_ONE_DEVICE"):  # rehearsal of the multi-rank plumbing on a one-GPU box only
         local_rank = 0
 
@@ -592,7 +590,7 @@ def main():
         print(json.dumps(out), flush=True)
     if dist:
         dist.barrier()
-        dist.destroy_process_group()
+        dist.close()
 
 
 if __name__ == "__main__":

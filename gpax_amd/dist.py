@@ -4,7 +4,8 @@
 
 Two drivers over the same compute phases:
   * ``DistributedStep.fit_predict``  -- production: one process per GPU, RCCL inside the library; the
-    NCCL unique id travels over ``torch.distributed`` (any backend), nothing else does.
+    NCCL unique id travels over the control plane (``gpax_amd._control`` sockets, or ``torch.distributed`` if the
+    caller initialised it), nothing else does.
   * ``LoopbackGroup``                -- validation on ONE GPU: P virtual ranks in one process, the
     transport played by device-to-device copies.  Used by tests/test_gpu_dist.py; not a fallback.
 """
@@ -153,16 +154,17 @@ class LoopbackGroup:
 
 class DistributedStep:
     """Production driver: this process is rank ``rank`` of ``nranks`` (one per GPU); RCCL moves the panel
-    factors inside ``gpx_dist_fit_predict``.  ``torch.distributed`` must be initialised (any backend): it
-    only carries the 128-byte NCCL unique id."""
+    factors inside ``gpx_dist_fit_predict``.  The 128-byte NCCL unique id travels over the active control plane:
+    ``gpax_amd._control`` (plain sockets; what ``bench.py`` uses: no second HIP runtime in the process) or, if the caller
+    initialised it, ``torch.distributed`` (any backend)."""
 
     def __init__(self, x, x_new, y_minus_m, device=None, nb=128, force_comm=False):
         """``force_comm``: create the RCCL communicator even at one rank, so that every collective of the driver
         runs (as a self-copy) -- how the RCCL calls are exercised on a one-GPU box (tests/test_gpu_dist.py)."""
-        import torch.distributed as dist
+        from gpax_amd import _control, parallel
 
-        self.rank = dist.get_rank() if dist.is_initialized() else 0
-        self.nranks = dist.get_world_size() if dist.is_initialized() else 1
+        cp = _control.active()
+        self.rank, self.nranks = parallel.world()
         self.core = Core(self.rank if device is None else device)
         self.core.set_option("nb", nb)
         self.r = _Rank(self.core, self.rank, self.nranks, x, x_new, y_minus_m)
@@ -173,7 +175,12 @@ class DistributedStep:
                 self.core._check(self.core._lib.gpx_dist_unique_id(buf), "gpx_dist_unique_id")
                 uid = [buf.raw]
             if self.nranks > 1:
-                dist.broadcast_object_list(uid, src=0)
+                if cp is not None:
+                    uid = [cp.broadcast(uid[0])]
+                else:
+                    import torch.distributed as dist
+
+                    dist.broadcast_object_list(uid, src=0)
             self.core._check(self.core._lib.gpx_dist_comm_init(self.core._h, uid[0], self.rank, self.nranks), "gpx_dist_comm_init")
 
     def fit_predict(self, params, m_new=None, new_noise=0.0):

@@ -1,4 +1,5 @@
-"""Multi-GPU sharding of the path (one process per GPU, ``torch.distributed`` for the control plane).
+"""Multi-GPU sharding of the path (one process per GPU; control plane = ``gpax_amd._control`` sockets when one is active,
+else ``torch.distributed`` if the caller initialised a process group -- e.g. gloo in the CPU tests).
 
 The reference has no distributed code at all (gpax/state.py:64 ``# TODO: multi-gpu support?``).  The
 path shards over INDEPENDENT units: gpax's ``vmap`` over hyper-parameter draws
@@ -13,7 +14,16 @@ import numpy as np
 
 
 def world():
-    """(rank, world_size) of the active process group, (0, 1) without one."""
+    """(rank, world_size) of the active control plane / process group, (0, 1) without one."""
+    from gpax_amd import _control
+
+    cp = _control.active()
+    if cp is not None:
+        return cp.rank, cp.world
+    import sys
+
+    if "torch" not in sys.modules and "torch.distributed" not in sys.modules:
+        return 0, 1   # never the one to import PyTorch (a second HIP runtime, DESIGN.md section 5)
     try:
         import torch.distributed as dist
 
@@ -41,6 +51,11 @@ def gather_draws(local, n_items, group=None):
     rank, ws = world()
     if ws == 1:
         return np.stack(local) if local else np.zeros((0,))
+    from gpax_amd import _control
+
+    cp = _control.active()
+    if cp is not None:
+        return _control.gather_arrays(cp, local, n_items, lambda r: partition_draws(n_items, r, ws))
     import torch
     import torch.distributed as dist
 
@@ -74,9 +89,15 @@ def map_draws_batched(fn_batch, n_items, group=None):
     outs = fn_batch(idx) if idx else None
     n_out = len(outs) if outs is not None else None
     if ws > 1:
-        import torch.distributed as dist
+        from gpax_amd import _control
 
-        counts = [None] * ws
-        dist.all_gather_object(counts, n_out, group=group)
+        cp = _control.active()
+        if cp is not None:
+            counts = cp.all_gather(n_out)
+        else:
+            import torch.distributed as dist
+
+            counts = [None] * ws
+            dist.all_gather_object(counts, n_out, group=group)
         n_out = next(c for c in counts if c is not None)
     return tuple(gather_draws(list(outs[k]) if outs is not None else [], n_items, group) for k in range(n_out))

@@ -77,3 +77,63 @@ def test_map_draws_batched_world_size_2_matches_serial(n_items):
 def test_single_process_path_is_identity():
     mu, = parallel.map_draws_batched(lambda idx: (np.array([[i, 2.0 * i] for i in idx]),), 4)
     assert np.array_equal(mu, np.array([[0, 0], [1, 2], [2, 4], [3, 6.0]]))
+
+
+# ---- the socket control plane (gpax_amd._control): what bench.py and gpax_amd.dist use at WORLD_SIZE > 1
+
+def _cp_worker(rank, ws, port, n_items, q):
+    import re
+    import sys
+
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="t")
+    import gpax_amd  # noqa: F401  (the library first, as bench.py does)
+    from gpax_amd import _control, _lib
+
+    _lib.load()
+    cp = _control.activate(_control.ControlPlane.from_env(timeout=60))
+    try:
+        assert parallel.world() == (rank, ws)
+        cp.barrier()
+        mx = cp.max(10.0 + rank)
+        uid = cp.broadcast(b"\x01" * 128 if rank == 0 else None)
+        calls = []
+
+        def fn_batch(idx):
+            calls.append(list(idx))
+            return (np.stack([np.random.default_rng(1000 + i).standard_normal(5) + i for i in idx]), np.stack([np.full((2, 3), float(i)) for i in idx]))
+
+        mu, y = parallel.map_draws_batched(fn_batch, n_items)
+        mine = parallel.partition_draws(n_items, rank, ws)
+        assert calls == ([mine] if mine else [])
+        hips = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if re.search(r"libamdhip64", ln)})
+        q.put((rank, mx, uid, mu, y, hips, "torch" in sys.modules))
+        cp.barrier()
+    finally:
+        cp.close()
+        _control.activate(None)
+
+
+@pytest.mark.parametrize("ws,n_items", [(2, 7), (3, 2), (2, 1)])
+def test_socket_control_plane_matches_serial_and_maps_one_hip_runtime(ws, n_items):
+    """bench.py / gpax_amd.dist at WORLD_SIZE > 1 run on ``gpax_amd._control`` (plain sockets): barrier, MAX, broadcast of
+    the NCCL unique id, and the gather behind ``parallel.map_draws_batched`` (incl. ranks that own no draw) -- and the
+    process keeps exactly ONE libamdhip64 mapped and never imports torch (``import torch.distributed`` maps PyTorch's
+    bundled HIP + HSA runtimes beside the /opt/rocm ones the library is bound to)."""
+    import multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cp_worker, args=(r, ws, port, n_items, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(ws)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref_mu = np.stack([np.random.default_rng(1000 + i).standard_normal(5) + i for i in range(n_items)])
+    ref_y = np.stack([np.full((2, 3), float(i)) for i in range(n_items)])
+    for rank, mx, uid, mu, y, hips, has_torch in got:
+        assert mx == 10.0 + ws - 1 and uid == b"\x01" * 128
+        assert np.array_equal(mu, ref_mu) and np.array_equal(y, ref_y)
+        assert len(hips) == 1 and not has_torch, (hips, has_torch)

@@ -5,7 +5,8 @@ For every block step k the band kernel's first phase (S = A_{k+1,k} W_k^T) can s
   W     potrf_diag(k) has published W_k                      (in-kernel flag; the time its flag went up, after its last instruction)
   Qpub  the panel stream's column updates of step k-1 have published their first block row (in-kernel counter; since round 3
         only row 2 of the band kernel waits for it)
-  bulk  the bulk launch that last wrote block (k+1,k+1) has ended (stream-level event in front of the band launch)
+  bulk  the bulk launch that last wrote block (k+1,k+1) has ended (stream-level event in front of the band launch);
+  Bpub  ... or, where that launch publishes its first block column first (round 3), the time that column was complete
   res   the band kernel itself is resident                    (its launch, behind whatever its stream waits for)
 The table gives each arrival relative to potrf_diag(k)'s end, names the LAST one, when the band kernel's phases S and U
 started, when potrf_diag(k+1) became resident (pres: its first instruction, before its wait) and when it started (next).
@@ -84,7 +85,7 @@ nblk = n // nb
 # "S started" (kind 3, beta 0) before potrf_start[k+1] and the first "resident" record after potrf_start[k] - 40 us
 steps = sorted(k for k in potrf_end if k + 1 in potrf_start)
 lines = []
-hdr = f"{'k':>3} {'potrf':>6} | arrivals relative to potrf_diag(k) end [us]: {'W':>5} {'Qpub':>7} {'bulk':>7} {'res':>7} | {'S':>6} {'U':>6} {'pres':>6} {'next':>6} | last to arrive"
+hdr = f"{'k':>3} {'potrf':>6} | arrivals relative to potrf_diag(k) end [us]: {'W':>5} {'Qpub':>7} {'bulk':>7} {'Bpub':>7} {'res':>7} | {'S':>6} {'U':>6} {'pres':>6} {'next':>6} | last to arrive"
 lines.append(hdr)
 last_count = {}
 for k in steps:
@@ -107,7 +108,9 @@ for k in steps:
     # bulk: the latest bulk launch that started before S and whose first column is <= k+1 (cf = (rows_total - M) / nb)
     bl = [g for g in gemms if g["role"] == "bulk" and g["end"] and (rows_total - g["M"]) // nb <= k + 1 and (S is None or g["start"] < S)]
     bulk = bl[-1]["end"] if bl else None
-    arr = {"W": potrf_pub.get(k, pe), "Qpub": qpub if os.environ.get("CP_QPUB_CRITICAL") else None, "bulk": bulk, "res": res}
+    bpub = bl[-1]["pub"] if bl and bl[-1].get("pub") else None   # its first block column published (round 3)
+    arr = {"W": potrf_pub.get(k, pe), "Qpub": qpub if os.environ.get("CP_QPUB_CRITICAL") else None,
+           "bulk": bpub if bpub is not None else bulk, "res": res}
     have = {kk: v for kk, v in arr.items() if v is not None}
     last = max(have, key=lambda kk: have[kk]) if have else "?"
     last_count[last] = last_count.get(last, 0) + 1
@@ -115,7 +118,7 @@ for k in steps:
     def rel(v):
         return f"{v - pe:7.1f}" if v is not None else "      -"
 
-    lines.append(f"{k:3d} {pe - potrf_start[k]:6.1f} | {'':47s} {potrf_pub.get(k, pe) - pe:5.1f} {rel(qpub)} {rel(bulk)} {rel(res)} | {rel(S)[1:]} {rel(U)[1:]} {rel(potrf_res.get(k + 1))[1:]} {nxt - pe:6.1f} | {last}")
+    lines.append(f"{k:3d} {pe - potrf_start[k]:6.1f} | {'':47s} {potrf_pub.get(k, pe) - pe:5.1f} {rel(qpub)} {rel(bulk)} {rel(bpub)} {rel(res)} | {rel(S)[1:]} {rel(U)[1:]} {rel(potrf_res.get(k + 1))[1:]} {nxt - pe:6.1f} | {last}")
 
 dur = np.array([potrf_end[k] - potrf_start[k] for k in sorted(potrf_end)])
 gap = np.array([potrf_start[k + 1] - potrf_end[k] for k in steps])
