@@ -309,9 +309,16 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
     for (; k0 + GEMM_BK < kend; k0 += GEMM_BK) chunk(k0, true, false, false);
     chunk(k0, false, false, true);
 #else
+#ifdef GEMM_LATE_C
+    // experiment: the C tile requested in the LAST chunk, when no prefetch register is live (128 VGPRs: a SIMD then holds three of
+    // these waves AND a wave of the one-pass / band kernels, which the 160-VGPR form cannot)
+    for (; k0 + GEMM_BK < kend; k0 += GEMM_BK) chunk(k0, true, false, false);
+    chunk(k0, false, HASC, true);
+#else
     for (; k0 + 2 * GEMM_BK < kend; k0 += GEMM_BK) chunk(k0, true, false, false);
     chunk(k0, true, HASC, false);         // second to last
     chunk(k0 + GEMM_BK, false, false, true);
+#endif
 #endif
   }
   GEMM_STAMP(13);
