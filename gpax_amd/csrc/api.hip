@@ -318,7 +318,6 @@ static int* option_slot(gpx_handle* h, const char* name) {
   if (!strcmp(name, "split_min_blocks")) return &h->split_min_blocks;
   if (!strcmp(name, "la_rows")) return &h->la_rows;
   if (!strcmp(name, "batch_group")) return &h->batch_group;
-  if (!strcmp(name, "chain_overlap")) return &h->chain_overlap;
   if (!strcmp(name, "bulk_first_col")) return &h->bulk_first_col;
   if (!strcmp(name, "debug_force_timeout")) return &h->debug_force_timeout;
   return nullptr;

@@ -184,7 +184,6 @@ struct PotrfLaunch {
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;   // resident start: sleep until *wait_flag >= wait_count
   unsigned* done_flag = nullptr;                                   // raised behind the last store of W
   unsigned long long wait_ticks = 25000000ull;                     // bound of the resident wait (100 MHz ticks: 0.25 s)
-  int any_order = 0;                                               // launch without the queue barrier (hipExtAnyOrderLaunch)
   int batch = 1;                                                   // blockIdx.x = draw
   int64_t sA = 0, sL = 0, sW = 0, s_info = 0, s_flag = 0;
 };
@@ -335,8 +334,6 @@ struct gpx_handle {
   int la_rows = 3072;    // look-ahead column updates use 64x64 tiles while at least this many rows remain below; 0 = never
   int batch_group = 4;   // batches of >= 4 draws: bulk updates grouped g panels at a time throughout (0: the single-draw thresholds)
   int bulk_first_col = 1;  // ungrouped bulk launches enumerate and publish their first block column first (schedule.hip)
-  int chain_overlap = 0;   // potrf_diag(k) is launched WITHOUT the queue barrier (it may start while potrf_diag(k-1) runs: its order is
-                           // carried by the device flags) in the last `chain_overlap` block columns; 0 = never
   int debug_force_timeout = 0;   // test hook: the next factorisation's first resident wait gives up at once (info = -7)
 
   // resident inputs (x and x_new are shared by the draws of a batch; r, m_new, hyp, noise are per draw)

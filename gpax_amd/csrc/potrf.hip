@@ -737,15 +737,14 @@ int launch_potrf_diag(gpx_handle* h, hipStream_t s, const PotrfLaunch& q) {
   p.sA = q.sA; p.sL = q.sL; p.sW = q.sW; p.s_info = q.s_info; p.s_flag = q.s_flag;
   if (q.batch < 1) { gpx_set_error(h, "potrf_diag: batch < 1"); return GPX_ERR_ARG; }
   const dim3 grid((unsigned)q.batch);
-  const unsigned fl = q.any_order ? hipExtAnyOrderLaunch : 0u;
   switch (q.nb) {
     case 64:
-      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, true>), grid, dim3(256), 0, s, nullptr, q.stop_event, fl, p);
-      else hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, false>), grid, dim3(256), 0, s, nullptr, q.stop_event, fl, p);
+      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, true>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
+      else hipExtLaunchKernelGGL((potrf_diag_kernel<64, 4, false>), grid, dim3(256), 0, s, nullptr, q.stop_event, 0, p);
       break;
     case 128:
-      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, true>), grid, dim3(512), 0, s, nullptr, q.stop_event, fl, p);
-      else hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, false>), grid, dim3(512), 0, s, nullptr, q.stop_event, fl, p);
+      if (q.done_flag) hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, true>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
+      else hipExtLaunchKernelGGL((potrf_diag_kernel<128, 8, false>), grid, dim3(512), 0, s, nullptr, q.stop_event, 0, p);
       break;
     default:
       gpx_set_error(h, "potrf_diag: nb must be 64 or 128");

@@ -363,7 +363,6 @@ struct SplitSchedule {
       if (resident && k >= 1) { p.wait_flag = flagsU + (k - 1); p.wait_count = n_signal; }
       if (chain2 && need_w && k + 1 < nblk) p.done_flag = flagsW + k;
       if (k == force_timeout_at && p.wait_flag) { p.wait_count = 0xffffffffu; p.wait_ticks = 2000ull; }
-      if (chain2 && p.wait_flag && k >= 2 && nblk - k <= h->chain_overlap) p.any_order = 1;
       prof_begin(h, PD, GPX_STAGE_POTRF_DIAG, B * (double)nb * nb * nb / 3.0 * 2.0, B * 3.0 * 8.0 * nb * nb);
       GPX_RET(launch_potrf_diag(h, PD, p));
       prof_end(h, PD);

@@ -240,6 +240,8 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *                  columns remain; 0 = never (28 / 40)
  *   "split_min_blocks" the split-panel schedule runs from this many block columns; below, one stream (3)
  *   "la_rows"      look-ahead column updates run on 64x64 tiles while at least this many rows remain below them; 0 = never (3072)
+ *   "bulk_first_col" ungrouped bulk launches enumerate and publish their first block column first, so that the next column
+ *                  update and the band kernel wait for that counter instead of the launch's end; 0 = completion events (1)
  *   "batch_group"  batched draws (gpx_fit_predict_batch, gpx_sample_batch) with four or more draws: 2 | 4 = the bulk updates are
  *                  grouped that many panels at a time from the first step to the last (a batch is throughput-bound throughout);
  *                  the arithmetic is that of a single-draw call with "pair_min" = 1 and "quad_min" = 2 (4) or 0 (2).

@@ -308,3 +308,26 @@ def test_fit_with_lockstep_chains_equals_sequential_chains():
     info = b.metadata["mcmc_info"]
     total = sum(i["num_grad_evals"] for i in info)
     assert info[0]["batched_calls"] < total and info[0]["batched_points"] == total    # fewer GPU calls than gradient evaluations
+
+
+@pytest.mark.parametrize("n,m", [(1500, 90), (4096, 300)])
+def test_first_column_publication_of_bulk_launches_does_not_move_a_bit(core, n, m):
+    """Option ``bulk_first_col`` (default on): ungrouped bulk launches enumerate their first block column first and those
+    tiles publish themselves, so the panel stream's next column update and the band kernel's phase 0 wait for that counter
+    instead of the launch's completion event.  Only the ORDER in which workgroups take tiles changes: same bits."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    x, y, xn, p = orc.synthetic_problem(n, 6, m, seed=n)
+    prm = gpax_amd.make_params(0, p["k_scale"], p["k_length"], None, p["k_noise"], p["k_jitter"])
+    core.set_train(x)
+    core.set_test(xn)
+    try:
+        core.set_option("bulk_first_col", 0)
+        ref = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
+        core.set_option("bulk_first_col", 1)
+        for _ in range(3):
+            got = core.fit_predict(prm, y - 1.0, np.ones(m), 0.0)
+            assert got[0] == ref[0] == 0 and got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
+    finally:
+        core.set_option("bulk_first_col", 1)
