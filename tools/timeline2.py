@@ -24,6 +24,8 @@ x = rng.uniform(-1, 1, (n, d)); xn = rng.uniform(-1, 1, (m, d)); y = rng.standar
 core = gpax_amd.Core(0)
 lib = _lib.load()
 core.set_train(x); core.set_test(xn); core.set_targets(y, np.ones(m))
+for kv in filter(None, os.environ.get("CP_OPTS", "").split(",")):   # e.g. CP_OPTS=pair_min=24,bulk_wait=1
+    core.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 p = gpax_amd.make_params(0, 1.0, 1.0, None, np.array([0.0067]), 1e-6)
 for _ in range(5):
     core.fit_predict_async(p, 0.0); core.fetch_results()
