@@ -29,7 +29,7 @@ _lib.LIB_PATH = os.path.join(root, "tools", "libgpx_hip_tl.so")
 import gpax_amd  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-d, m, nb = 8, 1000, 128
+d, m, nb = 8, int(os.environ.get("CP_M", "1000")), 128   # CP_M: test points (the border rows)
 rng = np.random.default_rng(0)
 x = rng.uniform(-1, 1, (n, d)); xn = rng.uniform(-1, 1, (m, d)); y = rng.standard_normal(n)
 core = gpax_amd.Core(0)
