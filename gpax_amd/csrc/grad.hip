@@ -29,6 +29,7 @@ struct GradArgs {
   const double* kinv;     // lower tiles valid, leading dimension ldk
   const double* alpha;    // (n)
   double* part;           // [gridDim.y][gridDim.x][NPV]
+  double* mirror;         // single workgroup per chunk (part IS the sums): the pinned host mirror of the sums, or NULL
   int64_t n, ldk, ntiles;
   int d, per_dim;
   // batched hyper-parameter draws (blockIdx.z = draw): per-draw strides in doubles; x is shared
@@ -207,12 +208,14 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(GradArgs g) {
   if (tid < NPV) {
     const double s = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
     g.part[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NPV + tid] = s;
+    if (g.mirror) g.mirror[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NPV + tid] = s;
   }
 }
 
 // sums[chunk][v] = sum over workgroups of part[chunk][wg][v], fixed association (strided partial sums per
 // thread, then a binary tree): bitwise reproducible for a given launch geometry
-__global__ __launch_bounds__(256) void grad_final_kernel(const double* part, double* sums, int nwg, int64_t s_part, int64_t s_sums) {
+__global__ __launch_bounds__(256) void grad_final_kernel(const double* part, double* sums, int nwg, int64_t s_part, int64_t s_sums,
+                                                         double* mirror) {
   __shared__ double sh[256];
   const int chunk = blockIdx.y, v = blockIdx.x, tid = threadIdx.x;
   part += (int64_t)blockIdx.z * s_part; sums += (int64_t)blockIdx.z * s_sums;
@@ -224,7 +227,10 @@ __global__ __launch_bounds__(256) void grad_final_kernel(const double* part, dou
     if (tid < off) sh[tid] += sh[tid + off];
     __syncthreads();
   }
-  if (tid == 0) sums[chunk * NPV + v] = sh[0];
+  if (tid == 0) {
+    sums[chunk * NPV + v] = sh[0];
+    if (mirror) mirror[chunk * NPV + v] = sh[0];   // single draw only (the caller passes NULL for a batch)
+  }
 }
 
 int grad_partials_per_chunk(void) { return NPV; }
@@ -233,8 +239,9 @@ int grad_chunk_dims(void) { return DC; }
 // part: device scratch of nchunk * nwg * NPV doubles; sums: device, nchunk * NPV doubles
 int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, const double* hyp, const double* kinv,
                        int64_t ldk, const double* alpha, int64_t n, int d, int per_dim, int nwg, double* part,
-                       double* sums, int batch, int64_t s_hyp, int64_t s_kinv, int64_t s_out) {
+                       double* sums, int batch, int64_t s_hyp, int64_t s_kinv, int64_t s_out, double* mirror_sums) {
   GradArgs g;
+  if (batch != 1) mirror_sums = nullptr;
   g.x = x; g.hyp = hyp; g.kinv = kinv; g.alpha = alpha; g.part = part;
   g.n = n; g.ldk = ldk; g.d = d; g.per_dim = per_dim;
   if (batch < 1) { gpx_set_error(h, "grad_reduce: batch < 1"); return GPX_ERR_ARG; }
@@ -249,6 +256,7 @@ int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, 
   // applies (the caller passes nwg = 1 for up to three tiles) a launch costs more than the three tiles
   const bool direct = nwg == 1;
   if (direct) g.part = sums;
+  g.mirror = direct ? mirror_sums : nullptr;
   // draw b: hyp + b s_hyp, kinv + b s_kinv, alpha and sums inside its result block (+ b s_out), part + b nchunk nwg NPV
   g.s_hyp = s_hyp; g.s_kinv = s_kinv; g.s_alpha = s_out; g.s_part = direct ? s_out : (int64_t)nchunk * nwg * NPV;
   dim3 grid((unsigned)nwg, (unsigned)nchunk, (unsigned)batch);
@@ -261,7 +269,7 @@ int launch_grad_reduce(gpx_handle* h, hipStream_t s, int kind, const double* x, 
   GPX_HIP_CHECK(h, hipGetLastError());
   if (direct) return GPX_OK;
   hipLaunchKernelGGL(grad_final_kernel, dim3(NPV, (unsigned)nchunk, (unsigned)batch), dim3(256), 0, s, part, sums, nwg,
-                     (int64_t)nchunk * nwg * NPV, s_out);
+                     (int64_t)nchunk * nwg * NPV, s_out, mirror_sums);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

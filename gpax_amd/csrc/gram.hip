@@ -40,6 +40,9 @@ struct GramArgs {
   int* zero_info;    // when set, workgroup (0,0) clears it (saves the factorisation a memset launch)
   unsigned* zero_flags; int n_zero_flags;   // likewise: the hand-over flags of the split-panel schedule
   int64_t s_out, s_hyp, s_noise, s_info, s_flags;   // per-draw strides of a batched launch (blockIdx.z = draw; x1 / x2 are shared)
+  // single draw, first launch of a step: the hyper-parameters arrive in the kernel arguments (hyp_n doubles: length[d], period[d],
+  // scalars) and workgroup (0,0) writes them to `hyp_out` (= d_hyp) for the kernels behind this one
+  int hyp_n; double* hyp_out; double hyp_in[GPX_HYP_INLINE];
 };
 
 template <int KIND, bool VEC2>
@@ -52,10 +55,15 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 
   const int tid = threadIdx.x;
   const int64_t i0 = (int64_t)blockIdx.y * GT, j0 = (int64_t)blockIdx.x * GT;
+  gpx_gptr hyp = (gpx_gptr)(uintptr_t)g.hyp, dsc = (gpx_gptr)(uintptr_t)g.dev_scalars;
+  if (g.hyp_n) {
+    hyp = gpx_kernarg_doubles(offsetof(GramArgs, hyp_in)); dsc = hyp + 2 * g.d;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid < g.hyp_n) g.hyp_out[tid] = hyp[tid];
+  }
   if (blockIdx.z) {   // draw z of a batch: its own hyper-parameters, output matrix, info word and flags
     const int64_t z = blockIdx.z;
-    g.out += z * g.s_out; g.hyp += z * g.s_hyp;
-    if (g.dev_scalars) g.dev_scalars += z * g.s_hyp;
+    g.out += z * g.s_out; hyp += z * g.s_hyp;
+    if (dsc) dsc += z * g.s_hyp;
     if (g.noise) g.noise += z * g.s_noise;
     if (g.zero_info) g.zero_info += z * g.s_info;
     if (g.zero_flags) g.zero_flags += z * g.s_flags;
@@ -78,8 +86,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
   for (int dc0 = 0; dc0 < g.d; dc0 += DC) {
     if (tid < DC) {
       int k = dc0 + tid;
-      len_s[tid] = k < g.d ? g.hyp[k] : 1.0;
-      per_s[tid] = k < g.d ? g.hyp[g.d + k] : 1.0;
+      len_s[tid] = k < g.d ? hyp[k] : 1.0;
+      per_s[tid] = k < g.d ? hyp[g.d + k] : 1.0;
     }
     // stage (scaled for RBF/Matern: x / lengthscale as gpax/kernels.py:45-46; raw for periodic)
 #pragma unroll
@@ -87,7 +95,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
       const int k = dc0 + lk + q;
       double a = 0.0, b = 0.0;
       if (k < g.d) {
-        const double len = g.hyp[k];
+        const double len = hyp[k];
         if (i0 + lrow < g.n1) a = g.x1[(i0 + lrow) * g.d + k];
         if (j0 + lrow < g.n2) b = g.x2[(j0 + lrow) * g.d + k];
         if (KIND != GPX_PERIODIC) { a = a / len; b = b / len; }
@@ -119,9 +127,9 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
 
   // hyper-parameter scalars: from device memory when the launch is part of a replayed hipGraph
   // (one captured graph then serves every hyper-parameter value), else by value
-  const double k_scale = g.dev_scalars ? g.dev_scalars[0] : g.k_scale;
-  const double noise_scalar = g.dev_scalars ? g.dev_scalars[1] : g.noise_scalar;
-  const double jitter = g.dev_scalars ? g.dev_scalars[2] : g.jitter;
+  const double k_scale = dsc ? dsc[0] : g.k_scale;
+  const double noise_scalar = dsc ? dsc[1] : g.noise_scalar;
+  const double jitter = dsc ? dsc[2] : g.jitter;
   const int64_t col = j0 + 2 * cj;
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
@@ -179,6 +187,12 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   g.k_scale = L.k_scale; g.noise_scalar = L.noise_scalar; g.jitter = L.jitter;
   g.col0 = L.col0; g.zero_info = L.zero_info; g.zero_flags = L.zero_flags; g.n_zero_flags = L.n_zero_flags;
   g.s_out = L.s_out; g.s_hyp = L.s_hyp; g.s_noise = L.s_noise; g.s_info = L.s_info; g.s_flags = L.s_flags;
+  g.hyp_n = 0; g.hyp_out = nullptr;
+  if (L.hyp_inline && L.hyp_inline_n > 0) {
+    if (L.batch != 1 || L.hyp_inline_n > GPX_HYP_INLINE || L.hyp_inline_n < 2 * L.d + 3) { gpx_set_error(h, "gram: inline hyper-parameters out of range"); return GPX_ERR_ARG; }
+    g.hyp_n = L.hyp_inline_n; g.hyp_out = const_cast<double*>(L.hyp);
+    for (int i = 0; i < L.hyp_inline_n; ++i) g.hyp_in[i] = L.hyp_inline[i];
+  }
   if (L.batch < 1 || L.batch > 65535) { gpx_set_error(h, "gram: batch out of range"); return GPX_ERR_ARG; }
   dim3 grid((unsigned)((L.n2 + GT - 1) / GT), (unsigned)((L.n1 + GT - 1) / GT), (unsigned)L.batch);
   const bool vec2 = (L.ld % 2 == 0) && ((reinterpret_cast<uintptr_t>(L.out) & 15) == 0);
@@ -214,14 +228,20 @@ struct BuildArgs {
   int64_t ident_row0;   // >= 0: rows [ident_row0, ident_row0 + n) are identity rows (the gradient path's border: they become U = L^-T)
   double* zero2;        // when set: a second matrix (same ld) whose rows >= npad are cleared by the same launch (the border of L)
   int64_t s_out, s_hyp, s_noise, s_r, s_info;   // per-draw strides of a batched launch (blockIdx.y = draw)
+  int hyp_n; double hyp_in[GPX_HYP_INLINE];     // as GramArgs: hyper-parameters in the kernel arguments, written to `hyp` by workgroup 0
 };
 
 template <int KIND>
 __global__ void build_small_kernel(BuildArgs g) {
   const int64_t row = blockIdx.x, col = threadIdx.x;
+  gpx_gptr hyp = (gpx_gptr)(uintptr_t)g.hyp, dsc = (gpx_gptr)(uintptr_t)g.dev_scalars;
+  if (g.hyp_n) {
+    hyp = gpx_kernarg_doubles(offsetof(BuildArgs, hyp_in)); dsc = hyp + 2 * g.d;
+    if (blockIdx.x == 0 && (int)threadIdx.x < g.hyp_n) const_cast<double*>(g.hyp)[threadIdx.x] = hyp[threadIdx.x];
+  }
   if (blockIdx.y) {
     const int64_t z = blockIdx.y;
-    g.out += z * g.s_out; g.hyp += z * g.s_hyp; g.dev_scalars += z * g.s_hyp;
+    g.out += z * g.s_out; hyp += z * g.s_hyp; dsc += z * g.s_hyp;
     if (g.noise) g.noise += z * g.s_noise;
     if (g.r) g.r += z * g.s_r;
     if (g.r_copy) g.r_copy += z * g.s_r;
@@ -252,14 +272,14 @@ __global__ void build_small_kernel(BuildArgs g) {
   const double* x2 = g.x + col * g.d;
   double acc = 0.0;
   for (int k = 0; k < g.d; ++k) {
-    const double len = g.hyp[k];
+    const double len = hyp[k];
     double a = x1[k], b = x2[k];
     if (KIND != GPX_PERIODIC) { a = a / len; b = b / len; }
     double d0 = a - b;
-    if (KIND == GPX_PERIODIC) d0 = sin(M_PI * d0 / g.hyp[g.d + k]) / len;
+    if (KIND == GPX_PERIODIC) d0 = sin(M_PI * d0 / hyp[g.d + k]) / len;
     acc = fma(d0, d0, acc);
   }
-  const double k_scale = g.dev_scalars[0], noise_scalar = g.dev_scalars[1], jitter = g.dev_scalars[2];
+  const double k_scale = dsc[0], noise_scalar = dsc[1], jitter = dsc[2];
   double kv;
   if (KIND == GPX_RBF) kv = k_scale * gpx_exp_neg(-0.5 * acc);
   else if (KIND == GPX_MATERN52) {
@@ -276,7 +296,8 @@ int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, 
                        const double* dev_scalars, const double* noise, const double* r, double* out, int64_t ld, int64_t n,
                        int64_t npad, int64_t m_rows, int64_t r_row, int64_t rows_total, int d, int diag_rule, int* zero_info,
                        unsigned* zero_flags, int n_zero_flags, int64_t ident_row0, double* zero2, double* r_copy, int batch,
-                       int64_t s_out, int64_t s_hyp, int64_t s_noise, int64_t s_r, int64_t s_info) {
+                       int64_t s_out, int64_t s_hyp, int64_t s_noise, int64_t s_r, int64_t s_info, const double* hyp_inline,
+                       int hyp_inline_n) {
   if (npad > 256 || npad <= 0 || !dev_scalars) { gpx_set_error(h, "build_small: at most 256 columns"); return GPX_ERR_ARG; }
   BuildArgs g;
   g.x = x; g.xnew = xnew; g.hyp = hyp; g.dev_scalars = dev_scalars; g.noise = noise; g.r = r; g.out = out; g.ld = ld;
@@ -284,6 +305,12 @@ int launch_build_small(gpx_handle* h, hipStream_t s, int kind, const double* x, 
   g.zero_info = zero_info; g.zero_flags = zero_flags; g.n_zero_flags = n_zero_flags;
   g.ident_row0 = ident_row0; g.zero2 = zero2; g.r_copy = r_copy;
   g.s_out = s_out; g.s_hyp = s_hyp; g.s_noise = s_noise; g.s_r = s_r; g.s_info = s_info;
+  g.hyp_n = 0;
+  if (hyp_inline && hyp_inline_n > 0) {
+    if (batch != 1 || hyp_inline_n > GPX_HYP_INLINE || hyp_inline_n < 2 * d + 3) { gpx_set_error(h, "build_small: inline hyper-parameters out of range"); return GPX_ERR_ARG; }
+    g.hyp_n = hyp_inline_n;
+    for (int i = 0; i < hyp_inline_n; ++i) g.hyp_in[i] = hyp_inline[i];
+  }
   if (batch > 1 && zero_flags) { gpx_set_error(h, "build_small: zero_flags is not batched"); return GPX_ERR_ARG; }
   const dim3 grid((unsigned)rows_total, (unsigned)batch), block((unsigned)(npad <= 64 ? 64 : (npad <= 128 ? 128 : 256)));
   switch (kind) {

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
                                                       int64_t c0, int64_t c1, double* part, int64_t m, int mode,
                                                       const double* U, double* alpha, int64_t gemv_ncols, int gemv_block0,
                                                       int64_t s_mat, int64_t s_out, int64_t s_zcopy, int64_t s_mnew, int64_t s_hyp,
-                                                      int64_t s_part) {
+                                                      int64_t s_part, double* mirror, const int* info_src, int64_t mirror_var_off) {
   if (blockIdx.y) {   // draw y of a batch
     const int64_t b = blockIdx.y;
     L += b * s_mat; if (z) z += b * s_mat; if (vt) vt += b * s_mat; if (U) U += b * s_mat;
@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
     double s = 0.0;
     for (int64_t k = row + lane; k < gemv_ncols; k += 64) s = fma(u[k], z[k], s);
     s = wave_sum(s);
-    if (lane == 0) alpha[row] = s;
+    if (lane == 0) {
+      alpha[row] = s;
+      if (mirror && mode != 1) mirror[GPX_OUT_HEAD + row] = s;   // alpha sits where the posterior mean would (api.hip: lml_grad_once)
+    }
     return;
   }
   if (blockIdx.x == 0) {
@@ -98,6 +101,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
       if (mode == 1) { part[0] = s1; part[1] = s2; }
       else if (mode == 2) { scal[0] = part[0] + s1; scal[1] = part[1] + s2; }
       else { scal[0] = s1; scal[1] = s2; }
+      if (mirror && mode != 1) {   // the pinned host mirror of the result block (every writer of info has finished: stream order)
+        mirror[0] = scal[0]; mirror[1] = scal[1];
+        reinterpret_cast<int*>(mirror + 8)[0] = __hip_atomic_load(info_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     return;
   }
@@ -114,8 +121,10 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* L, int64_t 
   if (threadIdx.x == 0) {
     if (mode == 1) { part[2 + row] = dot; part[2 + m + row] = ss; return; }
     if (mode == 2) { dot += part[2 + row]; ss += part[2 + m + row]; }
-    mean[row] = (m_new ? m_new[row] : 0.0) + dot;
-    var[row] = (dev_prior_diag ? dev_prior_diag[0] : prior_diag) - ss;
+    const double mu = (m_new ? m_new[row] : 0.0) + dot, vr = (dev_prior_diag ? dev_prior_diag[0] : prior_diag) - ss;
+    mean[row] = mu;
+    var[row] = vr;
+    if (mirror) { mirror[GPX_OUT_HEAD + row] = mu; mirror[GPX_OUT_HEAD + mirror_var_off + row] = vr; }
   }
 }
 
@@ -125,7 +134,8 @@ static int launch_epilogue_range(gpx_handle* h, hipStream_t s, const EpilogueLau
   hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(rows + 1 + gemv_blocks), (unsigned)e.batch), dim3(256), 0, s, e.L, e.ld, e.n, e.z, e.z_copy,
                      e.z_copy ? e.npad : e.n, e.scal, e.vt, e.vt_ld, e.m_new, e.prior_diag, e.dev_prior_diag, e.mean, e.var,
                      c0, c1, part, rows, mode, gemv_blocks ? e.gemv_U : nullptr, e.gemv_alpha, e.gemv_ncols, (int)(rows + 1),
-                     e.s_mat, e.s_out, e.s_zcopy, e.s_mnew, e.s_hyp, e.s_part);
+                     e.s_mat, e.s_out, e.s_zcopy, e.s_mnew, e.s_hyp, e.s_part, (mode != 1 && e.batch == 1) ? e.mirror : nullptr, e.info_src,
+                     e.mirror_var_off);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }

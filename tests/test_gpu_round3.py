@@ -331,3 +331,34 @@ def test_first_column_publication_of_bulk_launches_does_not_move_a_bit(core, n, 
             assert got[0] == ref[0] == 0 and got[1] == ref[1] and np.array_equal(got[2], ref[2]) and np.array_equal(got[3], ref[3])
     finally:
         core.set_option("bulk_first_col", 1)
+
+
+def test_results_through_the_pinned_mirror_across_growing_and_shrinking_problems(core):
+    """Single-draw steps hand their results to the host through a pinned mirror the last kernels write themselves, and up to
+    N = 1024 their hyper-parameters travel in the first launch's kernel arguments (api.hip: ensure_mirror, upload_params_batch).
+    Both must survive what re-allocates the pinned buffers around them -- a larger N (the upload ring grows), a larger M (the
+    mirror grows), a smaller problem afterwards -- and the interleaving of the two entry points that share the result block;
+    every step is checked against the oracle (gpax/gp.py:247-312 for the posterior, :145-151 for the log-marginal)."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    for kind, n, m, d in ((1, 30, 200, 1), (0, 1024, 100, 1), (0, 64, 700, 2), (1, 1100, 50, 3), (0, 40, 10, 1)):
+        x, r, rng = _problem(n, d, seed=n + m)
+        xn = rng.uniform(-1, 1, (m, d))
+        k_length = np.array([0.8])
+        for noise in (0.03, 0.05):   # two draws per size: the second reuses every buffer of the first
+            p = gpax_amd.make_params(kind, 1.1, k_length, None, np.array([noise]), 1e-6, True)
+            core.set_train(x); core.set_test(xn); core.set_targets(r, np.ones(m))
+            core.fit_predict_async(p, 0.0)
+            info, logp, mean, var = core.fetch_results()
+            info_g, logp_g, grads, alpha = core.lml_grad(p, r)
+            assert info == 0 and info_g == 0
+            prm = {"k_scale": 1.1, "k_length": k_length, "k_noise": noise, "k_jitter": 1e-6}
+            logp_ref, mean_ref, var_ref = orc.fit_predict(kind, x, r + 1.0, xn, prm, mean_value=1.0)
+            assert abs(logp - logp_ref) <= TOL_LOGP_REL * abs(logp_ref) and abs(logp_g - logp_ref) <= TOL_LOGP_REL * abs(logp_ref)
+            assert np.abs(mean - mean_ref).max() <= 1e-8 and np.abs(var - var_ref).max() <= 1e-8
+            _, g_ref, alpha_ref = orc.lml_grad(kind, x, r, 1.1, k_length, None, noise, 1e-6)
+            assert np.abs(alpha - alpha_ref).max() <= TOL_ALPHA_REL * np.abs(alpha_ref).max()
+            scale = max(np.abs(v).max() for v in g_ref.values())
+            for name, ref in g_ref.items():
+                assert np.abs(grads[name] - ref).max() <= TOL_GRAD_REL * scale, (name, n)

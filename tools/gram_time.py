@@ -4,6 +4,10 @@ GPX_GRAM_SLAB_MIN=1000000000 selects the 64 x 64-tile kernel (round 2), the defa
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpax_amd import _lib
+if os.environ.get("GPX_AB_LIB"):   # time an older build of the library (tools/ab/...)
+    os.environ["GPX_LIB_COMPAT"] = "1"
+    _lib.LIB_PATH = os.path.abspath(os.environ["GPX_AB_LIB"])
 import gpax_amd
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 d = int(sys.argv[2]) if len(sys.argv) > 2 else 8

@@ -2,6 +2,10 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpax_amd import _lib
+if os.environ.get("GPX_AB_LIB"):   # time an older build of the library (tools/ab/...)
+    os.environ["GPX_LIB_COMPAT"] = "1"
+    _lib.LIB_PATH = os.path.abspath(os.environ["GPX_AB_LIB"])
 import gpax_amd
 c = gpax_amd.Core(0)
 rng = np.random.default_rng(0)
