@@ -287,6 +287,7 @@ extern "C" int gpx_destroy(gpx_handle* h) {
                   h->d_S, h->d_cov, h->d_z, h->d_out, h->d_g1, h->d_g2,
                   h->d_gout, h->d_vec, h->d_A2, h->d_L2, h->d_W2, h->d_kinv, h->d_gpart, h->d_mini, h->d_eps, h->d_smp};
   for (void* b : bufs) if (b) (void)hipFree(b);
+  for (double* b : h->d_aug) if (b) (void)hipFree(b);
   if (h->h_pinned) (void)hipHostFree(h->h_pinned);
   if (h->h_up) (void)hipHostFree(h->h_up);
   if (h->h_mirror) (void)hipHostFree(h->h_mirror);
@@ -336,6 +337,8 @@ static int* option_slot(gpx_handle* h, const char* name) {
   if (!strcmp(name, "la_rows")) return &h->la_rows;
   if (!strcmp(name, "batch_group")) return &h->batch_group;
   if (!strcmp(name, "bulk_first_col")) return &h->bulk_first_col;
+  if (!strcmp(name, "bulk_stride")) return &h->bulk_stride;
+  if (!strcmp(name, "bulk_stride_first")) return &h->bulk_stride_first;
   if (!strcmp(name, "debug_force_timeout")) return &h->debug_force_timeout;
   return nullptr;
 }

@@ -7,16 +7,15 @@
 //   PeriodicKernel               gpax/kernels.py:152-168   (direct differences, sin)
 // including the diagonal rule `(k_noise + k_jitter) * eye(n)`.
 //
-// HBM-bound: the output is written exactly once (8 B/entry, 16 B per lane per store,
-// two full 512-B row segments per wave-instruction) and each 64-row X block is read
-// once per tile into LDS (coalesced 32-B pieces), so HBM traffic is the algorithmic
-// 8*n1*n2 + 8*(n1+n2)*d bytes (the X re-reads per tile are L2 hits).
-// Distances use direct differences (sum_k (a_k-b_k)^2): free of the cancellation of
-// the |a|^2-2ab+|b|^2 expansion, never negative (so no clip needed), and within
-// 1e-15 of the reference's expansion form (tests/test_oracle.py).
-// fp64 MFMA is NOT used here on purpose: on gfx950 v_mfma_f64 runs at the vector
-// fp64 rate, the inner dimension d is tiny, and the kernel is bound by HBM writes
-// and the fp64 exp, not by the distance arithmetic.
+// HBM-bound: the output is written exactly once (8 B/entry, 16 B per lane per store) and the inputs are read from L2,
+// so HBM traffic is the algorithmic 8*n1*n2 + 8*(n1+n2)*d bytes.
+// Two tile kernels:
+//   * gram_prep_kernel + gram_mfma_kernel (RBF / Matern, d <= 62; the default since round 3): the reference's own
+//     |a|^2 - 2ab + |b|^2 form as one augmented matrix product on v_mfma_f64_16x16x4_f64, clipped at zero -- see the
+//     comment in front of them;
+//   * gram_kernel: direct differences sum_k (a_k - b_k)^2 on the vector ALU with the X blocks staged in LDS (periodic
+//     kernels, whose distance is a sine per dimension, and d > 62; rounds 1-2 used it for every kernel).  The two forms
+//     agree to a few 1e-15 (tests/test_oracle.py).
 
 #include <stdlib.h>
 
@@ -44,6 +43,29 @@ struct GramArgs {
   // scalars) and workgroup (0,0) writes them to `hyp_out` (= d_hyp) for the kernels behind this one
   int hyp_n; double* hyp_out; double hyp_in[GPX_HYP_INLINE];
 };
+
+// sqrt(a) for a in the normal range (here a = r2 + 1e-12 >= 1e-12): libdevice's sequence -- v_rsq_f64, one coupled
+// Newton step on (g, h) = (sqrt a, 1 / (2 sqrt a)), two residual corrections -- without its rescaling of tiny arguments and
+// its zero / infinity classification (seven instructions of 22); the same bits for every argument the kernels produce
+__device__ __forceinline__ double gpx_sqrt_normal(const double a) {
+  const double y = __builtin_amdgcn_rsq(a);
+  double g = a * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, a), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, a), h, g);
+  return g;
+}
+
+template <int KIND>
+__device__ __forceinline__ double gram_value(const double r2, const double k_scale) {
+  if (KIND == GPX_RBF) return k_scale * gpx_exp_neg(-0.5 * r2);                       // kernels.py:123
+  if (KIND == GPX_PERIODIC) return k_scale * gpx_exp_neg(-2.0 * r2);                  // kernels.py:165
+  const double rr = gpx_sqrt_normal(r2 + 1e-12);                                       // kernels.py:142
+  const double s5r = 2.2360679774997896964 * rr;
+  const double poly = __builtin_fma(5.0 / 3.0, r2, __builtin_fma(2.2360679774997896964, rr, 1.0));
+  return k_scale * poly * gpx_exp_neg(-s5r);                                           // kernels.py:144
+}
 
 template <int KIND, bool VEC2>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
@@ -138,20 +160,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
     double kv[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const double r2 = acc[r][c];
-      double k;
-      if (KIND == GPX_RBF) {
-        k = k_scale * gpx_exp_neg(-0.5 * r2);               // kernels.py:123
-      } else if (KIND == GPX_MATERN52) {
-        const double rr = sqrt(r2 + 1e-12);                   // kernels.py:142
-        const double s5r = 2.2360679774997896964 * rr;             // 5**0.5 * r
-        // 1 + sqrt5 r + 5/3 r2 with the contractions hipcc chose for the plain expression in rounds 1-2, spelled out
-        // (the entries keep their bits whatever else in this function changes)
-        const double poly = __builtin_fma(5.0 / 3.0, r2, __builtin_fma(2.2360679774997896964, rr, 1.0));
-        k = k_scale * poly * gpx_exp_neg(-s5r);                    // kernels.py:144
-      } else {
-        k = k_scale * gpx_exp_neg(-2.0 * r2);               // kernels.py:165
-      }
+      double k = gram_value<KIND>(acc[r][c], k_scale);
       const int64_t grow = g.row_gid ? g.row_gid[row] : row;
       if (g.diag_rule && grow == g.col0 + col + c) {
         const double nz = g.noise ? g.noise[grow] : noise_scalar;
@@ -167,6 +176,253 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g) {
       if (col < g.n2) dst[0] = kv[0];
       if (col + 1 < g.n2) dst[1] = kv[1];
     }
+  }
+}
+
+// ---- RBF / Matern on the matrix cores (round 3) ------------------------------------------------------------------------
+// The reference forms the scaled squared distance as |a|^2 - 2 a.b + |b|^2, clipped at zero (gpax/kernels.py:39-51).  That
+// form is ONE small matrix product: with the augmented rows  a' = [-2 a/l, |a/l|^2, 1]  and  b' = [b/l, 1, |b/l|^2]
+// (d + 2 entries, zero-padded to a multiple of 4),  a' . b' = r2.  v_mfma_f64_16x16x4_f64 does it beside the vector ALU,
+// which in gram_kernel above spends 2 d instructions per entry on the differences and, per tile, scales its two 64-row
+// input blocks by fp64 divisions, stages them through LDS and meets at two barriers.  Measured (tools/gram_ablate.sh): with
+// the exponentials AND the stores removed a tile kernel that stages its own inputs still took 19 of 26 us at N = 4096 and
+// 159 of 250 us at N = 16384 -- the per-tile prologue, not the epilogue, was the larger half.  So:
+//   gram_prep_kernel   one thread per input row, once per launch: x / l (true division, as the reference), the norm summed in
+//                      ascending k, the augmented row written to a scratch array (a few hundred KB, L2-resident);
+//   gram_mfma_kernel   one 64 x 64 output tile per 256-thread workgroup, NO LDS and NO barrier: every lane loads its MFMA
+//                      operands straight from the augmented arrays (8 B per lane, 32-B row pieces), wave w owns rows
+//                      16 w .. 16 w + 15 as four 16 x 16 MFMA tiles whose B rows are dealt so that a lane's tiles 0/1 (2/3)
+//                      hold two ADJACENT columns:  tile t, lane column j  <->  output column 32 (t >> 1) + 2 j + (t & 1).
+//                      A lane then stores 16 B at a time and a wave instruction writes four 256-B row segments.  Lower
+//                      builds enumerate the lower triangle of tiles only (1-D grid).
+// Differences from gram_kernel's direct form: <= 4e-15 absolute in r2 for |x / l|^2 <= 16 -- the reference's own
+// arithmetic (tests/test_oracle.py pins both forms against each other; every K parity test holds its 1e-12).  The matrix
+// core accumulates over K as a chain of fused multiply-adds in ascending k (build_small_kernel below restates the sum on
+// the vector ALU and the two paths agree bit for bit, tests/test_gpu_round3.py).  Periodic kernels (a sine per dimension)
+// and d > GRAM_MFMA_DMAX keep gram_kernel.
+#define GRAM_MFMA_DMAX 62
+
+// the epilogue of one 64 x 64 tile held in MFMA accumulators (wave w: rows 16 w + lk + 4 r; tile t, lane column li <-> column
+// 32 (t >> 1) + 2 li + (t & 1)): clip, kernel function, diagonal rule, 16-B stores
+template <int KIND, bool VEC2>
+__device__ __forceinline__ void gram_tile_store(const GramArgs& g, const v4d (&acc)[4], const int64_t i0, const int64_t j0, const int w,
+                                                const int li, const int lk, const double k_scale, const double noise_scalar,
+                                                const double jitter, const int ablate) {
+  // the diagonal rule can only touch a tile that meets the diagonal (row_gid: rows carry global ids, any tile may)
+  const bool diag_tile = g.diag_rule && (g.row_gid || (i0 < g.col0 + j0 + GT && g.col0 + j0 < i0 + GT));
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int64_t row = i0 + 16 * w + lk + 4 * r;
+    if (row >= g.n1) continue;
+    double* const drow = g.out + row * g.ld;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const int64_t col = j0 + 32 * hf + 2 * li;
+      double kv[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) kv[c] = (ablate & 2) ? acc[2 * hf + c][r] : gram_value<KIND>(fmax(acc[2 * hf + c][r], 0.0), k_scale);   // clip (kernels.py:50)
+      if ((ablate & 1) && kv[0] + kv[1] != 12345.678) continue;
+      if (diag_tile) {
+        const int64_t grow = g.row_gid ? g.row_gid[row] : row;
+        const double add = (g.noise ? g.noise[grow] : noise_scalar) + jitter;                          // kernels.py:124-125
+        if (grow == g.col0 + col) kv[0] += add;
+        if (grow == g.col0 + col + 1) kv[1] += add;
+      }
+      if (VEC2 && col + 1 < g.n2) {
+        v2d v; v.x = kv[0]; v.y = kv[1];
+        *reinterpret_cast<v2d*>(drow + col) = v;
+      } else {
+        if (col < g.n2) drow[col] = kv[0];
+        if (col + 1 < g.n2) drow[col + 1] = kv[1];
+      }
+    }
+  }
+}
+
+// The same tile from the raw inputs, for launches of at most two rounds of workgroups (N <= ~5800 lower builds): no prep
+// launch in front -- at these sizes its ~4 us (a kernel boundary and a latency-bound kernel) are more than the per-tile
+// staging costs -- the workgroup scales its two 64-row blocks itself (the same divisions, the same ascending-k norm sums:
+// the same bits as gram_prep_kernel), through LDS.
+template <int KIND, bool VEC2>
+__global__ __launch_bounds__(256) void gram_mfma_lds_kernel(GramArgs g, const int dp, const int64_t ntiles, const int tri, const int64_t ntj,
+                                                            const int ablate) {
+  extern __shared__ __attribute__((aligned(16))) double gram_lds[];   // xs1[64][dp], xs2[64][dp]
+  double* const xs1 = gram_lds;
+  double* const xs2 = gram_lds + GT * dp;
+  const int tid = threadIdx.x;
+  gpx_gptr hyp = (gpx_gptr)(uintptr_t)g.hyp, dsc = (gpx_gptr)(uintptr_t)g.dev_scalars;
+  if (g.hyp_n) {
+    hyp = gpx_kernarg_doubles(offsetof(GramArgs, hyp_in)); dsc = hyp + 2 * g.d;
+    if (blockIdx.x == 0 && tid < g.hyp_n) g.hyp_out[tid] = hyp[tid];
+  }
+  if (blockIdx.z) {
+    const int64_t z = blockIdx.z;
+    g.out += z * g.s_out; hyp += z * g.s_hyp;
+    if (dsc) dsc += z * g.s_hyp;
+    if (g.noise) g.noise += z * g.s_noise;
+    if (g.zero_info) g.zero_info += z * g.s_info;
+    if (g.zero_flags) g.zero_flags += z * g.s_flags;
+  }
+  if (blockIdx.x == 0) {
+    if (g.zero_info && tid == 0) *g.zero_info = 0;
+    if (g.zero_flags) for (int i = tid; i < g.n_zero_flags; i += 256) g.zero_flags[i] = 0u;
+  }
+  const int64_t id = blockIdx.x;
+  int64_t ti, tj;
+  if (tri) {
+    ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > id) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+    tj = id - ti * (ti + 1) / 2;
+  } else {
+    ti = id / ntj; tj = id - ti * ntj;
+  }
+  const int64_t i0 = ti * GT, j0 = tj * GT;
+  if (g.lower_only && g.col0 + j0 > i0 + GT - 1) return;
+
+  // stage: the 64 x d blocks of x1 and x2 are contiguous in memory -- element e of the block is row e / d, dimension e % d
+  const int d = g.d, tot = GT * d;
+  const int64_t lim1 = (g.n1 - i0) * d, lim2 = (g.n2 - j0) * d;   // elements of the block that exist
+  const double* const b1 = g.x1 + i0 * d;
+  const double* const b2 = g.x2 + j0 * d;
+  for (int e = tid; e < tot; e += 256) {
+    const int row = e / d, k = e - row * d;
+    const double len = hyp[k];
+    const double a = e < lim1 ? b1[e] : 0.0, b = e < lim2 ? b2[e] : 0.0;
+    xs1[row * dp + k] = a / len;     // x / lengthscale (kernels.py:45-46)
+    xs2[row * dp + k] = b / len;
+  }
+  __syncthreads();
+  if (tid < 2 * GT) {
+    double* const xr = (tid < GT ? xs1 : xs2) + (tid & (GT - 1)) * dp;
+    double nrm = 0.0;
+    for (int k = 0; k < d; ++k) nrm = fma(xr[k], xr[k], nrm);
+    if (tid < GT) {
+      for (int k = 0; k < d; ++k) xr[k] *= -2.0;
+      xr[d] = nrm; xr[d + 1] = 1.0;
+    } else {
+      xr[d] = 1.0; xr[d + 1] = nrm;
+    }
+    for (int k = d + 2; k < dp; ++k) xr[k] = 0.0;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const double* const ap = xs1 + (16 * w + li) * dp + lk;
+  const double* const bp = xs2 + (2 * li) * dp + lk;
+  v4d acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int s4 = 0; s4 < dp; s4 += 4) {
+    const double a = ap[s4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const double b = bp[(32 * (t >> 1) + (t & 1)) * dp + s4];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+    }
+  }
+  const double k_scale = dsc ? dsc[0] : g.k_scale;
+  const double noise_scalar = dsc ? dsc[1] : g.noise_scalar;
+  const double jitter = dsc ? dsc[2] : g.jitter;
+  gram_tile_store<KIND, VEC2>(g, acc, i0, j0, w, li, lk, k_scale, noise_scalar, jitter, ablate);
+}
+
+// rows [0, n1p) of the grid: x1 -> aug1 (a' layout); rows [n1p, n1p + n2p): x2 -> aug2 (b' layout); rows beyond n are zero
+__global__ __launch_bounds__(256) void gram_prep_kernel(GramArgs g, const int dp, const int64_t n1p, const int64_t n2p, double* aug1,
+                                                        double* aug2, const int64_t s_aug) {
+  gpx_gptr hyp = (gpx_gptr)(uintptr_t)g.hyp;
+  if (g.hyp_n) {
+    hyp = gpx_kernarg_doubles(offsetof(GramArgs, hyp_in));
+    if (blockIdx.x == 0 && (int)threadIdx.x < g.hyp_n) g.hyp_out[threadIdx.x] = hyp[threadIdx.x];
+  }
+  if (blockIdx.z) { hyp += (int64_t)blockIdx.z * g.s_hyp; aug1 += (int64_t)blockIdx.z * s_aug; aug2 += (int64_t)blockIdx.z * s_aug; }
+  int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (row >= n1p + n2p) return;
+  const bool second = row >= n1p;
+  if (second) row -= n1p;
+  const int64_t n = second ? g.n2 : g.n1;
+  const double* const x = (second ? g.x2 : g.x1) + row * g.d;
+  double* const o = (second ? aug2 : aug1) + row * dp;
+  const int d = g.d;
+  if (row >= n) { for (int k = 0; k < dp; ++k) o[k] = 0.0; return; }
+  double nrm = 0.0;
+  int k0 = 0;
+  for (; k0 + 8 <= d; k0 += 8) {   // eight dimensions at a time: their loads are in flight together
+    double xv[8], lv[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { xv[q] = x[k0 + q]; lv[q] = hyp[k0 + q]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double a = xv[q] / lv[q];     // x / lengthscale (kernels.py:45-46)
+      nrm = fma(a, a, nrm);
+      o[k0 + q] = second ? a : -2.0 * a;
+    }
+  }
+  for (int k = k0; k < d; ++k) {
+    const double a = x[k] / hyp[k];
+    nrm = fma(a, a, nrm);
+    o[k] = second ? a : -2.0 * a;
+  }
+  o[d] = second ? 1.0 : nrm;
+  o[d + 1] = second ? nrm : 1.0;
+  for (int k = d + 2; k < dp; ++k) o[k] = 0.0;
+}
+
+template <int KIND, bool VEC2, int DP>   // DP: compile-time padded inner dimension (12, 20), or 0 = the run-time dp
+__global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const int dp_rt, const int64_t ntiles, const int tri, const int64_t ntj,
+                                                        const double* aug1, const double* aug2, const int64_t s_aug, const int ablate) {
+  const int dp = DP ? DP : dp_rt;
+  const int tid = threadIdx.x;
+  gpx_gptr dsc = (gpx_gptr)(uintptr_t)g.dev_scalars;
+  if (blockIdx.z) {
+    const int64_t z = blockIdx.z;
+    g.out += z * g.s_out;
+    if (dsc) dsc += z * g.s_hyp;
+    if (g.noise) g.noise += z * g.s_noise;
+    if (g.zero_info) g.zero_info += z * g.s_info;
+    if (g.zero_flags) g.zero_flags += z * g.s_flags;
+    aug1 += z * s_aug; aug2 += z * s_aug;
+  }
+  if (blockIdx.x == 0) {
+    if (g.zero_info && tid == 0) *g.zero_info = 0;
+    if (g.zero_flags) for (int i = tid; i < g.n_zero_flags; i += 256) g.zero_flags[i] = 0u;
+  }
+  const double k_scale = dsc ? dsc[0] : g.k_scale;
+  const double noise_scalar = dsc ? dsc[1] : g.noise_scalar;
+  const double jitter = dsc ? dsc[2] : g.jitter;
+  const int lane = tid & 63, w = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int la = (16 * w + li) * dp + lk, lb = (2 * li) * dp + lk;   // lane offsets inside the tile's 64 augmented rows
+
+  for (int64_t id = blockIdx.x; id < ntiles; id += gridDim.x) {
+    int64_t ti, tj;
+    if (tri) {   // row-major over the lower triangle of tiles
+      ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+      while (ti * (ti + 1) / 2 > id) --ti;
+      while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
+      tj = id - ti * (ti + 1) / 2;
+    } else {
+      ti = id / ntj; tj = id - ti * ntj;
+    }
+    const int64_t i0 = ti * GT, j0 = tj * GT;
+    if (g.lower_only && g.col0 + j0 > i0 + GT - 1) continue;   // (wave-uniform)
+
+    const double* const ap = aug1 + i0 * dp + la;
+    const double* const bp = aug2 + j0 * dp + lb;
+    v4d acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < (DP ? DP : 64); s4 += 4) {
+      if (!DP && s4 >= dp) break;
+      const double a = ap[s4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const double b = bp[(32 * (t >> 1) + (t & 1)) * dp + s4];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+      }
+    }
+
+    gram_tile_store<KIND, VEC2>(g, acc, i0, j0, w, li, lk, k_scale, noise_scalar, jitter, ablate);
   }
 }
 
@@ -201,13 +457,55 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
     if (vec2) hipExtLaunchKernelGGL((gram_kernel<KIND, true>), grid, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);  \
     else hipExtLaunchKernelGGL((gram_kernel<KIND, false>), grid, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);      \
   } while (0)
+  const int dp = (L.d + 2 + 3) / 4 * 4;
+  // tiles of the MFMA kernel: the lower triangle only where the launch builds the lower part of a square matrix
+  const int64_t nti = (L.n1 + GT - 1) / GT, ntj = (L.n2 + GT - 1) / GT;
+  const int tri = (L.lower_only && L.col0 == 0 && L.n1 == L.n2 && !L.row_gid) ? 1 : 0;
+  const int64_t ntiles = tri ? nti * (nti + 1) / 2 : nti * ntj;
+  static const int tpw_env = getenv("GPX_GRAM_TPW") ? atoi(getenv("GPX_GRAM_TPW")) : 0;   // diagnostic: tiles per workgroup
+  static const int ablate = getenv("GPX_GRAM_ABLATE") ? atoi(getenv("GPX_GRAM_ABLATE")) : 0;   // diagnostic: 1 = no stores, 2 = no exp
+  const int64_t tpw = tpw_env > 0 ? tpw_env : 1;
+  const dim3 mgrid((unsigned)((ntiles + tpw - 1) / tpw), 1u, (unsigned)L.batch);
+  const int64_t n1p = nti * GT, n2p = ntj * GT, s_aug = (n1p + n2p) * dp;
+  double* aug1 = nullptr; double* aug2 = nullptr;
+  static const bool direct_env = getenv("GPX_GRAM_DIRECT") != nullptr;   // diagnostic: time gram_kernel (tools/gram_ab.sh)
+  const bool mfma = L.d <= GRAM_MFMA_DMAX && !direct_env && L.kind != GPX_PERIODIC;
+  static const int lds_env = getenv("GPX_GRAM_LDS") ? atoi(getenv("GPX_GRAM_LDS")) : -1;   // diagnostic: 1 / 0 force the variant
+  const bool lds_variant = lds_env >= 0 ? lds_env != 0 : ntiles * L.batch <= 16 * (int64_t)h->prop.multiProcessorCount;
+  const size_t lds = (size_t)(2 * GT * dp) * sizeof(double);
+  const dim3 lgrid((unsigned)ntiles, 1u, (unsigned)L.batch);
+  if (mfma && !lds_variant) {
+    // the augmented rows of this launch: a ring of four scratch arrays, so that a launch on another stream that is still
+    // reading its own (the step's cross gram on the panel stream) is never overwritten
+    const int slot = h->aug_next; h->aug_next = (h->aug_next + 1) & 3;
+    GPX_RET(ensure(h, &h->d_aug[slot], &h->aug_cap[slot], s_aug * L.batch));
+    aug1 = h->d_aug[slot]; aug2 = aug1 + n1p * dp;
+    GramArgs gp = g;   // the prep launch is the step's first launch: it carries the inline hyper-parameters
+    g.hyp_n = 0; g.hyp_out = nullptr;
+    const dim3 pgrid((unsigned)((n1p + n2p + 255) / 256), 1u, (unsigned)L.batch);
+    hipExtLaunchKernelGGL(gram_prep_kernel, pgrid, dim3(256), 0, s, L.start_event, nullptr, 0, gp, dp, n1p, n2p, aug1, aug2, s_aug);
+  }
+#define GPX_GRAM_MFMA(KIND)                                                          \
+  do {                                                                               \
+    if (vec2 && dp == 12) hipExtLaunchKernelGGL((gram_mfma_kernel<KIND, true, 12>), mgrid, dim3(256), 0, s, nullptr, L.stop_event, 0, g, dp, ntiles, tri, ntj, aug1, aug2, s_aug, ablate);  \
+    else if (vec2 && dp == 20) hipExtLaunchKernelGGL((gram_mfma_kernel<KIND, true, 20>), mgrid, dim3(256), 0, s, nullptr, L.stop_event, 0, g, dp, ntiles, tri, ntj, aug1, aug2, s_aug, ablate);  \
+    else if (vec2) hipExtLaunchKernelGGL((gram_mfma_kernel<KIND, true, 0>), mgrid, dim3(256), 0, s, nullptr, L.stop_event, 0, g, dp, ntiles, tri, ntj, aug1, aug2, s_aug, ablate);  \
+    else hipExtLaunchKernelGGL((gram_mfma_kernel<KIND, false, 0>), mgrid, dim3(256), 0, s, nullptr, L.stop_event, 0, g, dp, ntiles, tri, ntj, aug1, aug2, s_aug, ablate);      \
+  } while (0)
+#define GPX_GRAM_MFMA_LDS(KIND)                                                      \
+  do {                                                                               \
+    if (vec2) hipExtLaunchKernelGGL((gram_mfma_lds_kernel<KIND, true>), lgrid, dim3(256), lds, s, L.start_event, L.stop_event, 0, g, dp, ntiles, tri, ntj, ablate);  \
+    else hipExtLaunchKernelGGL((gram_mfma_lds_kernel<KIND, false>), lgrid, dim3(256), lds, s, L.start_event, L.stop_event, 0, g, dp, ntiles, tri, ntj, ablate);      \
+  } while (0)
   switch (L.kind) {
-    case GPX_RBF: GPX_GRAM_LAUNCH(GPX_RBF); break;
-    case GPX_MATERN52: GPX_GRAM_LAUNCH(GPX_MATERN52); break;
+    case GPX_RBF: if (mfma && lds_variant) GPX_GRAM_MFMA_LDS(GPX_RBF); else if (mfma) GPX_GRAM_MFMA(GPX_RBF); else GPX_GRAM_LAUNCH(GPX_RBF); break;
+    case GPX_MATERN52: if (mfma && lds_variant) GPX_GRAM_MFMA_LDS(GPX_MATERN52); else if (mfma) GPX_GRAM_MFMA(GPX_MATERN52); else GPX_GRAM_LAUNCH(GPX_MATERN52); break;
     case GPX_PERIODIC: GPX_GRAM_LAUNCH(GPX_PERIODIC); break;
     default: gpx_set_error(h, "unknown kernel kind"); return GPX_ERR_ARG;
   }
 #undef GPX_GRAM_LAUNCH
+#undef GPX_GRAM_MFMA
+#undef GPX_GRAM_MFMA_LDS
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
 }
@@ -271,23 +569,32 @@ __global__ void build_small_kernel(BuildArgs g) {
   if (col >= g.n) { *dst = 0.0; return; }
   const double* x2 = g.x + col * g.d;
   double acc = 0.0;
-  for (int k = 0; k < g.d; ++k) {
-    const double len = hyp[k];
-    double a = x1[k], b = x2[k];
-    if (KIND != GPX_PERIODIC) { a = a / len; b = b / len; }
-    double d0 = a - b;
-    if (KIND == GPX_PERIODIC) d0 = sin(M_PI * d0 / hyp[g.d + k]) / len;
-    acc = fma(d0, d0, acc);
+  if (KIND != GPX_PERIODIC && g.d <= GRAM_MFMA_DMAX) {
+    // gram_mfma_kernel's arithmetic, operation for operation: scaled inputs, their norms summed in ascending k, then the
+    // augmented dot product  sum_k (-2 a_k) b_k + |a|^2 * 1 + 1 * |b|^2  as the chain of fused multiply-adds the matrix
+    // core runs over K (ascending k from a zero accumulator), clipped at zero
+    double na = 0.0, nb_ = 0.0;
+    for (int k = 0; k < g.d; ++k) {
+      const double len = hyp[k];
+      const double a = x1[k] / len, b = x2[k] / len;
+      na = fma(a, a, na); nb_ = fma(b, b, nb_);
+      acc = fma(-2.0 * a, b, acc);
+    }
+    acc = fma(na, 1.0, acc);
+    acc = fma(1.0, nb_, acc);
+    acc = fmax(acc, 0.0);
+  } else {
+    for (int k = 0; k < g.d; ++k) {
+      const double len = hyp[k];
+      double a = x1[k], b = x2[k];
+      if (KIND != GPX_PERIODIC) { a = a / len; b = b / len; }
+      double d0 = a - b;
+      if (KIND == GPX_PERIODIC) d0 = sin(M_PI * d0 / hyp[g.d + k]) / len;
+      acc = fma(d0, d0, acc);
+    }
   }
   const double k_scale = dsc[0], noise_scalar = dsc[1], jitter = dsc[2];
-  double kv;
-  if (KIND == GPX_RBF) kv = k_scale * gpx_exp_neg(-0.5 * acc);
-  else if (KIND == GPX_MATERN52) {
-    const double rr = sqrt(acc + 1e-12);
-    const double s5r = 2.2360679774997896964 * rr;
-    const double poly = __builtin_fma(5.0 / 3.0, acc, __builtin_fma(2.2360679774997896964, rr, 1.0));   // as in gram_kernel
-    kv = k_scale * poly * gpx_exp_neg(-s5r);
-  } else kv = k_scale * gpx_exp_neg(-2.0 * acc);
+  double kv = gram_value<KIND>(acc, k_scale);
   if (diag_row && row == col) kv += ((g.noise ? g.noise[row] : noise_scalar) + jitter);
   *dst = kv;
 }

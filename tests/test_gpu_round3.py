@@ -362,3 +362,60 @@ def test_results_through_the_pinned_mirror_across_growing_and_shrinking_problems
             scale = max(np.abs(v).max() for v in g_ref.values())
             for name, ref in g_ref.items():
                 assert np.abs(grads[name] - ref).max() <= TOL_GRAD_REL * scale, (name, n)
+
+
+def test_gram_on_the_matrix_cores_variants_agree_bitwise_and_match_the_oracle(core):
+    """RBF / Matern grams run as an augmented matrix product on fp64 MFMA (gram.hip: the reference's own |a|^2 - 2ab + |b|^2
+    form, gpax/kernels.py:39-51, clipped at zero) in two variants -- a self-staging tile kernel for launches of at most two
+    rounds of workgroups and a prep launch + LDS-free tile kernel beyond -- and, up to 256 points, inside the one-launch
+    build of the bordered matrix.  A given entry must not depend on which variant built it (a batched call and a single-draw
+    call of the same problem pick different variants), and every variant holds the 1e-12 of the K parity tests."""
+    import gpax_amd
+    from oracle import gp_oracle as orc
+
+    rng = np.random.default_rng(5)
+    for kind, d in ((gpax_amd.RBF, 8), (gpax_amd.MATERN52, 16), (gpax_amd.RBF, 3), (gpax_amd.MATERN52, 62)):
+        n_big, n_small = 4200, 300    # 66 x 66 = 4356 tiles (> 16 per CU: the prep variant) against 5 x 5 (self-staging)
+        x = rng.uniform(-1, 1, (n_big, d))
+        ell = rng.uniform(0.7, 1.6, d)
+        p = gpax_amd.make_params(kind, 1.3, ell, None, np.array([0.05]), 1e-6, True)
+        k_big = core.gram(p, x, x)
+        k_small = core.gram(p, x[:n_small], x[:n_small])
+        blk = k_big[:n_small, :n_small].copy()
+        blk[np.diag_indices(n_small)] = k_small[np.diag_indices(n_small)]   # (the diagonal rule is keyed on the shapes: both carry it)
+        assert np.array_equal(np.diag(k_big)[:n_small], np.diag(k_small))
+        assert np.array_equal(blk, k_small), (kind, d)
+        rows = rng.choice(n_big, 200, replace=False)
+        ref = orc.gram(kind, x[rows], x, 1.3, ell, None, np.array([0.05]), 1e-6, False)
+        got = k_big[rows].copy()
+        got[np.arange(200), rows] -= 0.05 + 1e-6
+        assert np.abs(got - ref).max() <= 1e-12, (kind, d)
+    # beyond 62 dimensions the direct-difference kernel takes over; ragged shapes through both tile kernels
+    for n1, n2, d in ((130, 70, 63), (130, 70, 100), (700, 650, 5), (4500, 70, 4)):
+        x1, x2 = rng.uniform(-1, 1, (n1, d)), rng.uniform(-1, 1, (n2, d))
+        ell = rng.uniform(0.7, 1.6, d) * np.sqrt(d / 4.0)
+        for kind in (gpax_amd.RBF, gpax_amd.MATERN52):
+            p = gpax_amd.make_params(kind, 0.9, ell, None, np.array([0.0]), 0.0, False)
+            assert np.abs(core.gram(p, x1, x2) - orc.gram(kind, x1, x2, 0.9, ell, None, np.array([0.0]), 0.0, False)).max() <= 1e-12, (n1, n2, d, kind)
+
+
+def test_gram_of_coincident_and_far_points(core):
+    """The expansion form can come out a few 1e-16 below zero for coincident points (the reference clips, gpax/kernels.py:50):
+    duplicates must give exactly k_scale (RBF) or the Matern value at r = 1e-6, far points underflow to zero without a NaN."""
+    import gpax_amd
+
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-1, 1, (150, 8))
+    x[75:] = x[:75]                         # every point twice
+    for kind in (gpax_amd.RBF, gpax_amd.MATERN52):
+        p = gpax_amd.make_params(kind, 2.0, 0.3, None, np.array([0.0]), 0.0, False)
+        k = core.gram(p, x, x)
+        assert np.isfinite(k).all() and (k >= 0).all()
+        dup = k[np.arange(75), np.arange(75) + 75]
+        if kind == gpax_amd.RBF:
+            assert np.abs(dup - 2.0).max() <= 1e-14
+        else:
+            assert np.abs(dup - 2.0 * (1 + np.sqrt(5) * 1e-6) * np.exp(-np.sqrt(5) * 1e-6)).max() <= 1e-10
+    far = np.vstack([np.zeros((1, 8)), np.full((1, 8), 1000.0)])
+    k = core.gram(gpax_amd.make_params(gpax_amd.RBF, 1.0, 0.5, None, np.array([0.0]), 0.0, False), far, far)
+    assert np.array_equal(k, np.eye(2))
