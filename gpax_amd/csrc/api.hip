@@ -337,8 +337,6 @@ static int* option_slot(gpx_handle* h, const char* name) {
   if (!strcmp(name, "la_rows")) return &h->la_rows;
   if (!strcmp(name, "batch_group")) return &h->batch_group;
   if (!strcmp(name, "bulk_first_col")) return &h->bulk_first_col;
-  if (!strcmp(name, "bulk_stride")) return &h->bulk_stride;
-  if (!strcmp(name, "bulk_stride_first")) return &h->bulk_stride_first;
   if (!strcmp(name, "debug_force_timeout")) return &h->debug_force_timeout;
   return nullptr;
 }

@@ -37,13 +37,6 @@ struct GemmArgs {
   // publish themselves (write-through stores + one count into `signal`): the consumers of a bulk update's first block column
   // -- the panel stream's next column update, the chain's band kernel -- need not wait for the whole launch to end
   int first_col; int64_t map_nti;
-  // stride_tiles > 0 (bulk instantiation, 1-D map): the STRIDED lazy update -- the launch covers the block columns c0, c0 + G,
-  // c0 + 2 G, ... of the trapezoid only (each `first_col` tiles wide, from its diagonal block down; stride_tiles = G x first_col),
-  // block column by block column; the first one publishes (first_col semantics above) when `signal` is set
-  int stride_tiles;
-  // first_lone: the first block column of a strided launch was visited one step ago -- it takes the K range [first_koff, K) only
-  // (the last panel) and the strided columns start right behind it
-  int first_lone; int64_t first_koff;
   // batched hyper-parameter draws: blockIdx.z = draw, per-draw strides (0: shared)
   int64_t sA, sB, sC, s_flag, s_info;
   // block-cyclic row distribution (distributed factorisation): local row m is global row
@@ -159,27 +152,7 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
     int64_t id = blockIdx.x, ntj = g.map_ntj, shift = 0;
     int64_t ti = 0, tj = 0;
     bool mapped = false;
-    if (ROLE == 0 && g.stride_tiles > 0) {
-      // block column j starts at tile row / column j * stride_tiles and holds fc * rj - fc (fc - 1) / 2 tiles (rj tile rows);
-      // inside it: row-major, row r holds min(r + 1, fc) tiles
-      const int64_t fc = g.first_col, tri = fc * (fc - 1) / 2, tri1 = fc * (fc + 1) / 2;
-      int64_t rj = g.map_nti, j = 0, off = 0, cnt = fc * rj - tri;
-      while (id >= cnt) {
-        const int64_t step = (j == 0 && g.first_lone) ? fc : g.stride_tiles;
-        id -= cnt; ++j; off += step; rj -= step; cnt = fc * rj - tri;
-      }
-      if (id < tri1) {
-        ti = (int64_t)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
-        while (ti * (ti + 1) / 2 > id) --ti;
-        while ((ti + 1) * (ti + 2) / 2 <= id) ++ti;
-        tj = id - ti * (ti + 1) / 2;
-      } else {
-        ti = fc + (id - tri1) / fc; tj = (id - tri1) % fc;
-      }
-      ti += off; tj += off;
-      mapped = true; first_part = (j == 0) && g.signal != nullptr;
-      if (j == 0 && g.first_lone) { g.A += g.first_koff; g.B += g.first_koff; g.K -= g.first_koff; }   // the first block column lacks the last panel only
-    } else if (ROLE == 0 && g.first_col > 0) {
+    if (ROLE == 0 && g.first_col > 0) {
       const int64_t fc = g.first_col, tri1 = fc * (fc + 1) / 2, n1 = fc * g.map_nti - fc * (fc - 1) / 2;
       if (id < n1) {   // row-major over the first fc tile columns: row r holds min(r + 1, fc) tiles
         if (id < tri1) {
@@ -400,6 +373,16 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   GEMM_TL_END();
 }
 
+// (The STRIDED lazy update -- the bulk launch of step k visits only the block columns k+3, k+3+G, k+3+2G, ... and applies
+// the panels max(0, k-G+1) .. k to them in one K = G nb pass, so that every hand-over and the per-step distribution of the
+// work are those of the ungrouped schedule while the tiles are K = G nb tiles and each C tile is read and written once per
+// G panels; with the first column visited one step earlier too, so that its published tiles stay K = nb tiles -- was written
+// in round 3, passed the parity tests and measured SLOWER: N = 4096 G = 4: 1.54-1.58 vs 1.49-1.52 ms per step, the bulk
+// kernel's summed time 1.05 vs 0.89 ms per step (30.9 vs 35.6 TFLOP/s in situ); G = 2: 1.48-1.49 (a tie); G = 8: 1.88;
+// N = 8192 G = 4: 6.03-6.15 vs 5.91-5.95 with the quad grouping (42.5 vs 45.5 TFLOP/s), profiles/r03_bulk_strided_lazy.txt.
+// A launch with a quarter of the tiles, each living four times as long, leaves the chip's 768 slots partly empty at N = 4096
+// (240-500 tiles per launch) and runs 3 instead of 2.5 rounds at N = 8192; the K = 512 rate of 64-67 TFLOP/s needs launches
+// of many rounds.  Removed.)
 // (A streaming variant -- 768 resident workgroups taking tiles from a device counter, the next tile's first operand
 // chunk requested during the last chunk of the current one so that only a workgroup's first tile starts cold -- was
 // written and measured: 41.9 vs 46.1 TFLOP/s at M=4736 N=3712 K=128, 1.91 vs 1.76 ms per N = 4096 step.  Like a
@@ -432,6 +415,11 @@ struct TileOp {
 };
 
 // resident start: one lane polls (bounded: 0.25 s), one agent-scope acquire, the barrier releases the loads
+// (A pipelined poll -- four flag loads in flight ~64 cycles apart, each tested as it returns, instead of load / compare / sleep /
+// clock read with one load in flight -- was measured in round 3 at all three global-flag waits of the chain: 0.307-0.312 vs
+// 0.307-0.312 ms at N = 1024, 0.584-0.607 vs 0.580-0.582 at N = 2048, 1.507-1.545 vs 1.498-1.532 at N = 4096
+// (profiles/r03_pipelined_poll_ab.txt): the time a hand-over takes is the producer's write-through stores and the consumer's
+// operand loads, not the detection of the flag.  Not kept.)
 __device__ __forceinline__ void onepass_wait(const unsigned* f1, unsigned c1, const unsigned* f2, unsigned c2, int* info) {
   if (!f1 && !f2) return;
   if (threadIdx.x == 0) {
@@ -670,7 +658,7 @@ static void fill_args(GemmArgs& g, const GemmLaunch& L) {
   g.row_off = L.row_off; g.col_off = L.col_off; g.lower = L.lower; g.b_lower_tri = L.b_lower_tri;
   g.cyc_P = L.cyc_P; g.cyc_r = L.cyc_r; g.cyc_nb = L.cyc_nb;
   g.a_upper_tri = L.a_upper_tri;
-  g.map_S = 0; g.map_ntj = 0; g.first_col = 0; g.map_nti = 0; g.stride_tiles = 0; g.first_koff = 0; g.first_lone = 0;
+  g.map_S = 0; g.map_ntj = 0; g.first_col = 0; g.map_nti = 0;
   g.sA = L.sA; g.sB = L.sB; g.sC = L.sC; g.s_flag = L.s_flag; g.s_info = L.s_info;
   g.signal = L.signal; g.signal_m = L.signal_m; g.wait_flag = L.wait_flag; g.wait_count = L.wait_count; g.wait_info = L.wait_info;
   g.wait_flag2 = L.wait_flag2; g.wait_count2 = L.wait_count2; g.wait_m = L.wait_m;
@@ -721,7 +709,7 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
   // first `signal_m` rows only)
   const bool big_signal = !L.small_tile && L.beta != 0.0 && L.signal && !L.wait_flag &&
                           ((L.role == 1 && L.signal_m > 0 && L.signal_m % 64 == 0) ||
-                           (L.role == 0 && (L.first_col > 0 || L.stride_cols > 0) && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && L.N / 64 > L.first_col));
+                           (L.role == 0 && L.first_col > 0 && L.lower && L.row_off == L.col_off && L.cyc_P <= 1 && L.M >= L.N && L.N / 64 > L.first_col));
   if ((L.signal || L.wait_flag) && !(L.small_tile && (L.K == 128 || L.K == 64)) && !big_signal) {
     gpx_set_error(h, "gemm_nt: signal is served by the one-pass kernel and the 64x64 look-ahead kernel only");
     return GPX_ERR_ARG;
@@ -738,20 +726,7 @@ int launch_gemm_nt(gpx_handle* h, hipStream_t s, const GemmLaunch& L) {
     const int64_t nti = L.M / 64, ntj = L.N / 64;
     g.map_S = -1; g.map_ntj = ntj; g.map_nti = nti;
     if (L.first_col > 0 && L.role == 0 && L.beta != 0.0 && L.signal && ntj > L.first_col) g.first_col = L.first_col;
-    int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
-    if (L.stride_cols > 0) {   // strided lazy update: every stride_cols-th block column (col_tiles tiles wide) of the trapezoid
-      if (L.role != 0 || L.beta == 0.0 || L.col_tiles <= 0 || ntj % L.col_tiles) { gpx_set_error(h, "gemm_nt: strided update contract violated"); return GPX_ERR_ARG; }
-      const int64_t fc = L.col_tiles, tri = fc * (fc - 1) / 2;
-      g.first_col = (int)fc; g.stride_tiles = (int)(L.stride_cols * fc);
-      if (!(L.signal && ntj > fc)) g.signal = nullptr;
-      g.first_koff = L.first_koff; g.first_lone = L.first_lone;
-      if (L.first_koff < 0 || L.first_koff >= L.K || L.first_koff % GEMM_BK) { gpx_set_error(h, "gemm_nt: strided update contract violated (first_koff)"); return GPX_ERR_ARG; }
-      ntiles = 0;
-      for (int64_t c = 0, rj = nti, j = 0; c < ntj; ++j) {
-        const int64_t step = (j == 0 && L.first_lone) ? fc : g.stride_tiles;
-        ntiles += fc * rj - tri; c += step; rj -= step;
-      }
-    }
+    const int64_t ntiles = ntj * (ntj + 1) / 2 + (nti - ntj) * ntj;
     const dim3 tg((unsigned)ntiles, 1u, (unsigned)L.batch);
     if (L.beta != 0.0 && L.role == 1) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true, 1>), tg, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);
     else if (L.beta != 0.0) hipExtLaunchKernelGGL((gemm_nt_kernel<64, 64, true>), tg, dim3(256), 0, s, L.start_event, L.stop_event, 0, g);

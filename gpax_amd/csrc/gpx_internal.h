@@ -151,10 +151,6 @@ struct GemmLaunch {
   unsigned* signal = nullptr;
   int64_t signal_m = 0;   // > 0: only the tiles whose first row is below signal_m publish and count (the rest store plainly)
   int first_col = 0;      // bulk launch (role 0, 1-D tile map): enumerate the first `first_col` tile columns first; they publish and count into `signal`
-  // bulk launch (role 0, 1-D tile map): the strided lazy update -- only the block columns 0, stride_cols, 2 stride_cols, ... of the
-  // trapezoid (each col_tiles 64-wide tiles), the first one publishing into `signal` (when set) like first_col
-  int64_t stride_cols = 0; int64_t col_tiles = 0;
-  int first_lone = 0; int64_t first_koff = 0;   // first_lone: the first block column takes the K range [first_koff, K) only and the strided ones start right behind it
   // one-pass path: the kernel is launched early and sleeps until *wait_flag >= wait_count (a producer that is
   // still running publishes its output with write-through stores and then raises the flag)
   const unsigned* wait_flag = nullptr; unsigned wait_count = 0;
@@ -363,9 +359,6 @@ struct gpx_handle {
   double hyp_host[GPX_HYP_INLINE]; int hyp_host_n = 0;   // the draw's hyper-parameters, not uploaded yet: the next first launch carries them
   bool hyp_defer = false;     // set by the entry points whose first launch can carry them (upload_params_batch then skips the copy)
   int bulk_first_col = 1;  // ungrouped bulk launches enumerate and publish their first block column first (schedule.hip)
-  int bulk_stride_first = 1;   // strided bulk update: column k+3 is visited at step k-1 too, so that its (published) tiles at step k are K = nb tiles
-  int bulk_stride = 4;     // the strided lazy bulk update: block column c gets the panels it lacks every bulk_stride-th step in ONE
-                           // K = bulk_stride x nb pass (and all of them at step c - 3, when the look-ahead reaches it); 0 = every column every step
   int debug_force_timeout = 0;   // test hook: the next factorisation's first resident wait gives up at once (info = -7)
 
   // resident inputs (x and x_new are shared by the draws of a batch; r, m_new, hyp, noise are per draw)

@@ -411,15 +411,19 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const int dp
     v4d acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int s4 = 0; s4 < (DP ? DP : 64); s4 += 4) {
-      if (!DP && s4 >= dp) break;
+    auto kstep = [&](const int s4) __attribute__((always_inline)) {
       const double a = ap[s4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const double b = bp[(32 * (t >> 1) + (t & 1)) * dp + s4];
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
       }
+    };
+    if constexpr (DP > 0) {
+#pragma unroll
+      for (int s4 = 0; s4 < DP; s4 += 4) kstep(s4);   // every operand load of the tile in flight before the first MFMA
+    } else {
+      for (int s4 = 0; s4 < dp; s4 += 4) kstep(s4);
     }
 
     gram_tile_store<KIND, VEC2>(g, acc, i0, j0, w, li, lk, k_scale, noise_scalar, jitter, ablate);

@@ -211,16 +211,6 @@ struct SplitSchedule {
   std::vector<char> t_pending;
   std::vector<unsigned> t_pub;        // > 0: the bulk launch of step k publishes its first block column (flagsB[k] counts to this)
   int64_t pair_min, quad_min;
-  // The strided lazy bulk update ("bulk_stride" = G > 0): what the chain and the panel stream need from the bulk stream at
-  // step k is ONE block column -- column k+3, current through panel k, before the look-ahead window reaches it.  Every other
-  // column may lag.  So the bulk launch of step k visits the block columns k+3, k+3+G, k+3+2G, ... only and applies the
-  // panels max(0, k-G+1) .. k to them in one K = G nb pass: every column is visited every G-th step (all the panels since its
-  // last visit), and for the last time at step c-3.  The flops, the per-step distribution of the work and every hand-over
-  // are those of the ungrouped schedule (no group ends, no near blocks, no stall of the chain); the tiles are K = G nb tiles
-  // (the bulk kernel: 44 TFLOP/s alone at K = 128, 64-67 at K = 512) and each C tile is read and written once per G panels.
-  // Replaces the pair / quad grouping where it applies (not on the gradient path: its border rows are activated block by
-  // block, and a lazily applied panel would read rows of L that were never written).
-  int64_t stride = 0;
   int64_t last_t = -1;        // last group end (panels <= last_t are in every column >= last_t+3: by Q's near block and T's bulk launch)
   int64_t group_end = -1;     // the step at which T acts next
   int64_t q_waited_t = -1;    // the T launch (its step) Q has already waited for
@@ -275,9 +265,7 @@ struct SplitSchedule {
     // instead of 40 TFLOP/s and cut the passes over the trailing matrices g-fold).  Measured at N = 4096, 16 draws:
     // 40.5 -> 45.7 TFLOP/s aggregate.  The grouping is what a single-draw call does with "pair_min" = g / 4,
     // "quad_min" = g / 2, bit for bit; "batch_group" = 0 keeps the single-draw thresholds.
-    stride = (h->bulk_stride >= 2 && !kinv && tri_base < 0 && nb % 64 == 0) ? h->bulk_stride : 0;
-    if (stride) { pair_min = 0; quad_min = 0; }
-    if (M.batch >= 4 && h->batch_group >= 2 && !kinv && !stride) {
+    if (M.batch >= 4 && h->batch_group >= 2 && !kinv) {
       pair_min = 1;
       quad_min = h->batch_group >= 4 ? 2 : 0;
     }
@@ -630,30 +618,19 @@ struct SplitSchedule {
     const int64_t rows = c.rows_at(k), nbulk = nblk - (k + 3 + near_cols);
     if (nbulk > 0) {
       GPX_HIP_CHECK(h, hipStreamWaitEvent(T, h->ev_panel[(size_t)k], 0));
-      const int64_t kfirst = stride ? std::max<int64_t>(0, k - stride + 1) : last_t + 1, npan = k - kfirst + 1;
+      const int64_t kfirst = last_t + 1, npan = k - last_t;
       const int64_t cf = k + 3 + near_cols, br = cf * nb, bm = rows - br, nc = nbulk * nb;
       GemmLaunch t = c.update(br, bm, cf, nbulk, kfirst, npan, false);
-      if (stride) { t.stride_cols = stride; t.col_tiles = nb / 64; t.first_lone = h->bulk_stride_first ? 1 : 0; t.first_koff = t.first_lone ? (npan - 1) * nb : 0; }
       // ungrouped steps of the fused chain: the first block column (the only part of this launch the next step's column
       // update and band kernel need) is enumerated first and publishes itself
-      if (fuse_band && !kinv && (npan == 1 || stride) && near_cols == 0 && nbulk >= 2 && nb % 64 == 0 && h->bulk_first_col) {
+      if (fuse_band && !kinv && npan == 1 && near_cols == 0 && nbulk >= 2 && nb % 64 == 0 && h->bulk_first_col) {
         const int64_t fc = nb / 64, nti = bm / 64;
         t.first_col = (int)fc; t.signal = flagsB + k;
         t_pub[(size_t)k] = (unsigned)(fc * nti - fc * (fc - 1) / 2);
       }
-      double entries = trapezoid_entries(bm, nc);
-      int64_t nc_read = nc;   // rows of L read as the B operand
-      if (stride) {
-        entries = 0.0; nc_read = 0;
-        int64_t j = 0;
-        for (int64_t cc = cf; cc < nblk; ++j) {
-          const bool lone = j == 0 && t.first_lone;
-          entries += trapezoid_entries(rows - cc * nb, nb) * (lone ? (double)nb / (double)t.K : 1.0); nc_read += nb;
-          cc += lone ? 1 : stride;
-        }
-      }
+      const double entries = trapezoid_entries(bm, nc);
       // profiled: the kernel's own dispatch timestamps (what rocprofv3 reports), the hand-over event recorded behind it
-      const bool timed = prof_pair(h, GPX_STAGE_TRAILING, B * 2.0 * entries * t.K, B * 8.0 * (2.0 * entries + (double)(bm + nc_read) * t.K),
+      const bool timed = prof_pair(h, GPX_STAGE_TRAILING, B * 2.0 * entries * t.K, B * 8.0 * (2.0 * entries + (double)(bm + nc) * t.K),
                                    &t.start_event, &t.stop_event);
       // timed (profile mode 3): the timing stop event, attached to the kernel's own dispatch, IS the hand-over event -- a
       // second record behind the launch delayed every consumer of the bulk update and stretched the measured step by 10 %

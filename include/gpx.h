@@ -242,11 +242,6 @@ int gpx_profile_get(gpx_handle* h, int stage, double* total_ms, int64_t* launche
  *   "la_rows"      look-ahead column updates run on 64x64 tiles while at least this many rows remain below them; 0 = never (3072)
  *   "bulk_first_col" ungrouped bulk launches enumerate and publish their first block column first, so that the next column
  *                  update and the band kernel wait for that counter instead of the launch's end; 0 = completion events (1)
- *   "bulk_stride"  the strided lazy bulk update (round 3): block column c of the trailing matrix receives the panels it lacks
- *                  only every bulk_stride-th step, in ONE K = bulk_stride x nb pass of the bulk kernel, and everything it still
- *                  lacks at step c - 3, when the look-ahead window reaches it -- the per-step work and every hand-over of the
- *                  ungrouped schedule, at the bulk kernel's K = 512 rate and a quarter of its C traffic; replaces "pair_min" /
- *                  "quad_min" / "batch_group" where it applies (fit+predict and sampling; not the gradient path).  0 = off (4)
  *   "batch_group"  batched draws (gpx_fit_predict_batch, gpx_sample_batch) with four or more draws: 2 | 4 = the bulk updates are
  *                  grouped that many panels at a time from the first step to the last (a batch is throughput-bound throughout);
  *                  the arithmetic is that of a single-draw call with "pair_min" = 1 and "quad_min" = 2 (4) or 0 (2).
