@@ -383,6 +383,13 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
 // A launch with a quarter of the tiles, each living four times as long, leaves the chip's 768 slots partly empty at N = 4096
 // (240-500 tiles per launch) and runs 3 instead of 2.5 rounds at N = 8192; the K = 512 rate of 64-67 TFLOP/s needs launches
 // of many rounds.  Removed.)
+// (The same idea for the border rows alone -- the launch leaves the test points' rows, 42-57 % of its tiles at N = 4096 / M = 1000,
+// out of the trapezoid beyond its first block column and updates them in a rectangular segment over every G-th block column
+// with the G panels those columns lack, inside the SAME launch, so that no launch gets shorter of tiles -- was measured too:
+// G = 4 at N = 4096: the bulk kernel's summed time 1.01 vs 0.89 ms per step (31.3 vs 35.3 TFLOP/s), the step 1.50-1.60 vs
+// 1.47-1.60; G = 2 a tie; N = 8192 41-42 vs 42-43 TFLOP/s (profiles/r03_bulk_lazy_border.txt).  In these launches a K = 512 tile
+// is simply a tile that holds its slot four times as long; the per-chunk stalls of a lone wave (5.4k cycles per 32 columns of
+// K against 2k of MFMA work) are what three resident workgroups per CU hide from one another, whatever K is.  Removed.)
 // (A streaming variant -- 768 resident workgroups taking tiles from a device counter, the next tile's first operand
 // chunk requested during the last chunk of the current one so that only a workgroup's first tile starts cold -- was
 // written and measured: 41.9 vs 46.1 TFLOP/s at M=4736 N=3712 K=128, 1.91 vs 1.76 ms per N = 4096 step.  Like a
