@@ -210,6 +210,23 @@ __device__ __forceinline__ void gram_tile_store(const GramArgs& g, const v4d (&a
                                                 const double jitter, const int ablate) {
   // the diagonal rule can only touch a tile that meets the diagonal (row_gid: rows carry global ids, any tile may)
   const bool diag_tile = g.diag_rule && (g.row_gid || (i0 < g.col0 + j0 + GT && g.col0 + j0 < i0 + GT));
+  if (VEC2 && !diag_tile && !ablate && i0 + GT <= g.n1 && j0 + GT <= g.n2) {
+    // a full tile off the diagonal (all but ~2 N / 64 of them): no per-lane bounds or diagonal tests, one 32-bit lane offset
+    // on a wave-uniform row base
+    double* const base = g.out + (i0 + 16 * w) * g.ld + j0;
+    const unsigned lo = (unsigned)(lk * (int)g.ld + 2 * li);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        v2d v;
+        v.x = gram_value<KIND>(fmax(acc[2 * hf][r], 0.0), k_scale);
+        v.y = gram_value<KIND>(fmax(acc[2 * hf + 1][r], 0.0), k_scale);
+        *reinterpret_cast<v2d*>(base + (int64_t)(4 * r) * g.ld + 32 * hf + lo) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int64_t row = i0 + 16 * w + lk + 4 * r;
@@ -467,7 +484,11 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   const int tri = (L.lower_only && L.col0 == 0 && L.n1 == L.n2 && !L.row_gid) ? 1 : 0;
   const int64_t ntiles = tri ? nti * (nti + 1) / 2 : nti * ntj;
   static const int tpw_env = getenv("GPX_GRAM_TPW") ? atoi(getenv("GPX_GRAM_TPW")) : 0;   // diagnostic: tiles per workgroup
-  static const int ablate = getenv("GPX_GRAM_ABLATE") ? atoi(getenv("GPX_GRAM_ABLATE")) : 0;   // diagnostic: 1 = no stores, 2 = no exp
+  static const int ablate_env = getenv("GPX_GRAM_ABLATE") ? atoi(getenv("GPX_GRAM_ABLATE")) : 0;   // diagnostic: 1 = no stores, 2 = no exp, 4 / 8 = no fast epilogue
+  // the branch-free epilogue of full off-diagonal tiles issues its stores 10 % faster -- which helps up to N = 16384 (N = 4096:
+  // 24.0 -> 21.5 us, N = 16384: 235 -> 228 us, same box) and HURTS a multi-gigabyte write stream (N = 32768, 4.3 GB: 940-980 ->
+  // 1070-1130 us on three boxes): above 2 GiB of output the tiles keep the branchy epilogue (bit 8)
+  const int ablate = ablate_env | ((double)ntiles * GT * GT * 8.0 * L.batch > 2147483648.0 ? 8 : 0);
   const int64_t tpw = tpw_env > 0 ? tpw_env : 1;
   const dim3 mgrid((unsigned)((ntiles + tpw - 1) / tpw), 1u, (unsigned)L.batch);
   const int64_t n1p = nti * GT, n2p = ntj * GT, s_aug = (n1p + n2p) * dp;
