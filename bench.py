@@ -347,7 +347,7 @@ def main():
         g_avg = gr["ms"] * 1e-3 / max(gr["launches"], 1)
         g_bytes = gr["bytes"] / max(gr["launches"], 1)
         out["roofline_gram"] = {
-            "kernel": "gram_kernel (tiled pairwise distance + RBF epilogue)",
+            "kernel": "gram_mfma_lds_kernel (N <= ~5800) / gram_prep_kernel + gram_mfma_kernel: scaled squared distances as one augmented fp64-MFMA product + RBF epilogue; lower 64x64 tiles",
             "bound": "hbm",
             "achieved": g_bytes / g_avg * 1e-9 if g_avg > 0 else 0.0,
             "peak": HBM_PEAK_GBS,
