@@ -390,6 +390,15 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
 // 1.47-1.60; G = 2 a tie; N = 8192 41-42 vs 42-43 TFLOP/s (profiles/r03_bulk_lazy_border.txt).  In these launches a K = 512 tile
 // is simply a tile that holds its slot four times as long; the per-chunk stalls of a lone wave (5.4k cycles per 32 columns of
 // K against 2k of MFMA work) are what three resident workgroups per CU hide from one another, whatever K is.  Removed.)
+// (TWO operand chunks in flight -- a second register set taking every other chunk, the first two chunks requested together at
+// the start of the tile, the C tile at the second-to-last chunk, so that every load but the first has two chunks of MFMAs to
+// arrive in -- was measured stand-alone in round 3: at two workgroups per CU (232 VGPRs unconstrained) 41.9 vs 45.7 TFLOP/s at
+// M=4736 N=3712 K=128, 54.0 vs 58.3 at K=512, a tie on a 117-tile launch where every wave is alone on its SIMD; at three per CU
+// it spills 60 registers (32.7 TFLOP/s): profiles/r03_gemm_deep_prefetch.txt.  The lone wave's 1.7k cycles per chunk beside its
+// 2k of MFMA work are the LDS round trips and the two barriers of a chunk, not the operands' arrival.  Its by-product --
+// operand addresses as a wave-uniform base + one 32-bit lane offset, 160 -> 132 VGPRs at the same stand-alone speed -- lost in
+// situ like the 128-VGPR form of round 2 (N = 4096: 1.48-1.54 vs 1.478-1.50 ms, N = 8192 +0.5 %,
+// profiles/r03_gemm_uniform_addressing_ab.txt: a bulk wave that leaves room on its SIMD gets a neighbour).  Both removed.)
 // (A streaming variant -- 768 resident workgroups taking tiles from a device counter, the next tile's first operand
 // chunk requested during the last chunk of the current one so that only a workgroup's first tile starts cold -- was
 // written and measured: 41.9 vs 46.1 TFLOP/s at M=4736 N=3712 K=128, 1.91 vs 1.76 ms per N = 4096 step.  Like a
