@@ -10,6 +10,11 @@ R=$PWD
 OUT=$R/gpurun_out/refresh
 rm -rf $OUT; mkdir -p $OUT
 echo "HEAD ${GPX_HEAD:-?}  $(date -u +%FT%TZ)" > $OUT/STAMP
+# the diagnostic builds the tools below need (git-ignored binaries: a fresh checkout does not have them)
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+[ -x tools/peaks ] || $HIPCC --offload-arch=gfx950 -O3 -o tools/peaks tools/peaks.hip > $OUT/build_tools.log 2>&1
+[ -x tools/potrf_stamps ] || $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o tools/potrf_stamps tools/potrf_stamps.hip >> $OUT/build_tools.log 2>&1
+[ -f tools/libgpx_hip_tl.so ] || make -C gpax_amd/csrc timeline -j8 >> $OUT/build_tools.log 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"; tail -c 200 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
