@@ -391,7 +391,7 @@ struct gpx_handle {
   double* d_z = nullptr; int64_t z_cap = 0; bool have_z = false;  // z = L^-1 r (npad)
 
   // scratch of the stateless gpx_gram and of the vector back-substitution
-  double* d_aug[4] = {nullptr, nullptr, nullptr, nullptr}; int64_t aug_cap[4] = {0, 0, 0, 0}; int aug_next = 0;   // gram.hip: augmented input rows of the MFMA gram kernel (ring)
+  double* d_aug[4] = {nullptr, nullptr, nullptr, nullptr}; int64_t aug_cap[4] = {0, 0, 0, 0};   // gram.hip: augmented input rows of the MFMA gram kernel, one array per stream (chain, panel, bulk, any other)
   double* d_g1 = nullptr; int64_t g1_cap = 0;
   double* d_g2 = nullptr; int64_t g2_cap = 0;
   double* d_gout = nullptr; int64_t gout_cap = 0;

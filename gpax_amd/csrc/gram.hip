@@ -500,9 +500,9 @@ int launch_gram(gpx_handle* h, hipStream_t s, const GramLaunch& L) {
   const size_t lds = (size_t)(2 * GT * dp) * sizeof(double);
   const dim3 lgrid((unsigned)ntiles, 1u, (unsigned)L.batch);
   if (mfma && !lds_variant) {
-    // the augmented rows of this launch: a ring of four scratch arrays, so that a launch on another stream that is still
-    // reading its own (the step's cross gram on the panel stream) is never overwritten
-    const int slot = h->aug_next; h->aug_next = (h->aug_next + 1) & 3;
+    // the augmented rows of this launch: one scratch array per stream of the handle (launches of one stream run one after
+    // the other; the step's K build on the chain stream and its cross gram on the panel stream may overlap)
+    const int slot = s == h->s_main ? 0 : (s == h->s_far ? 1 : (s == h->s_trail ? 2 : 3));
     GPX_RET(ensure(h, &h->d_aug[slot], &h->aug_cap[slot], s_aug * L.batch));
     aug1 = h->d_aug[slot]; aug2 = aug1 + n1p * dp;
     GramArgs gp = g;   // the prep launch is the step's first launch: it carries the inline hyper-parameters
