@@ -379,6 +379,11 @@ __device__ __forceinline__ void potrf_flow(const double* A, int64_t lda, double*
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int fr = lane & 15, fk = lane >> 4;
+  // 1/l_jj, zero slots, epochs and flags start at zero (the tiles themselves are written by their owners) -- cleared BEFORE the
+  // resident wait: a block that starts asleep has nothing else to do, and behind the flag only the loads are left
+  for (int t = tid; t < NT * (DT_STRIDE - DT_RINV); t += NW * 64)
+    DT[(t / (DT_STRIDE - DT_RINV)) * DT_STRIDE + DT_RINV + t % (DT_STRIDE - DT_RINV)] = 0.0;
+  for (int t = tid; t < (NLOW + NT + 1) / 2 + 1; t += NW * 64) reinterpret_cast<double*>(fin)[t] = 0.0;
   if (wait_flag) {
     POTRF_TL(5, col0);
     if (tid == 0) {
@@ -394,10 +399,6 @@ __device__ __forceinline__ void potrf_flow(const double* A, int64_t lda, double*
   }
   POTRF_TL(1, col0);
   GPX_STAMP(0);
-  // 1/l_jj, zero slots, epochs and flags start at zero (the tiles themselves are written by their owners)
-  for (int t = tid; t < NT * (DT_STRIDE - DT_RINV); t += NW * 64)
-    DT[(t / (DT_STRIDE - DT_RINV)) * DT_STRIDE + DT_RINV + t % (DT_STRIDE - DT_RINV)] = 0.0;
-  for (int t = tid; t < (NLOW + NT + 1) / 2 + 1; t += NW * 64) reinterpret_cast<double*>(fin)[t] = 0.0;
 
   // ---- wave w loads block row w (tiles (w, 0..w)); the loads are in flight across the barrier
   const int r4 = lane >> 2, c4 = (lane & 3) * 4;
