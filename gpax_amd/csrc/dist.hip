@@ -72,6 +72,9 @@ static hipStream_t bulk_stream(gpx_handle* h) {
 
 // ---------------------------------------------------------------------------------- layout
 // global row blocks: [0, nblk) the matrix, [nblk, nblk + eblk) the border (k_cross rows, then r)
+// leading dimension of the K-contiguous group buffers: GPX_DIST_GMAX panels side by side (rows exactly 4 KiB apart; 16 or 32
+// doubles of padding measured no different: 37.2-37.7 ms per one-rank N = 16384 step either way)
+static inline int64_t group_ld(int64_t nb) { return (int64_t)GPX_DIST_GMAX * nb; }
 static inline int64_t owner_of(const DistState& d, int64_t i) { return i % d.P; }
 static inline int64_t slot_of(const DistState& d, int64_t i) { return i / d.P; }
 static inline int64_t nloc_of(const DistState& d, int r) { return (d.RB - r + d.P - 1) / d.P; }
@@ -101,7 +104,12 @@ __global__ void dist_unpermute_kernel(double* panel, const double* recv, int64_t
   const int64_t s0 = k >= r ? (k - r) / P + 1 : 0;
   const double* src = recv + ((int64_t)r * chunk_rows + (i / P - s0) * nb) * nb;
   double* dst = panel + (int64_t)blockIdx.x * nb * nb;
-  for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) dst[e] = src[e];
+  // 16 B per lane, the block split over gridDim.y workgroups (one workgroup copying 128 KB eight bytes at a time took 31 us
+  // per launch beside the bulk update: profiles/r03_kernel_stats_dist_one_rank.csv)
+  const int per = nb * nb / 2 / (int)gridDim.y;
+  const v2d* s2 = reinterpret_cast<const v2d*>(src) + (int64_t)blockIdx.y * per;
+  v2d* d2 = reinterpret_cast<v2d*>(dst) + (int64_t)blockIdx.y * per;
+  for (int e = threadIdx.x; e < per; e += blockDim.x) d2[e] = s2[e];
 }
 
 // the same chunks into a group buffer: block row i (absolute) -> rows [i nb, (i+1) nb), columns [slot nb, (slot+1) nb) of G (ld = ldg)
@@ -113,7 +121,12 @@ __global__ void dist_unpermute_group_kernel(double* G, int64_t ldg, int slot, co
   const int64_t s0 = k >= r ? (k - r) / P + 1 : 0;
   const double* src = recv + ((int64_t)r * chunk_rows + (i / P - s0) * nb) * nb;
   double* dst = G + i * nb * ldg + (int64_t)slot * nb;
-  for (int e = threadIdx.x; e < nb * nb; e += blockDim.x) dst[(int64_t)(e / nb) * ldg + e % nb] = src[e];
+  const int rows_per = nb / (int)gridDim.y, hw = nb / 2;   // rows of the block per workgroup; 16-B pieces per row
+  const int r0 = (int)blockIdx.y * rows_per;
+  for (int e = threadIdx.x; e < rows_per * hw; e += blockDim.x) {
+    const int rr = r0 + e / hw, c2 = e % hw;
+    *reinterpret_cast<v2d*>(dst + (int64_t)rr * ldg + 2 * c2) = *reinterpret_cast<const v2d*>(src + (int64_t)rr * nb + 2 * c2);
+  }
 }
 
 __global__ __launch_bounds__(256) void dist_logdet_kernel(const double* L, int64_t ld, int64_t nslots, int P, int rank,
@@ -162,8 +175,8 @@ extern "C" int gpx_dist_configure(gpx_handle* h, int rank, int nranks, const dou
   GPX_RET(dist_ensure(h, &D.panel2, &D.panel2_cap, D.RB * nb * nb));
   // grouped bulk updates: two K-contiguous group buffers, (RB nb) rows x (GPX_DIST_GMAX nb) columns each -- the gathered
   // panels of a group side by side, indexed by ABSOLUTE block row, so that one K = g nb pass can apply them all
-  GPX_RET(dist_ensure(h, &D.group[0], &D.group_cap[0], D.RB * nb * (int64_t)GPX_DIST_GMAX * nb));
-  GPX_RET(dist_ensure(h, &D.group[1], &D.group_cap[1], D.RB * nb * (int64_t)GPX_DIST_GMAX * nb));
+  GPX_RET(dist_ensure(h, &D.group[0], &D.group_cap[0], D.RB * nb * group_ld(nb)));
+  GPX_RET(dist_ensure(h, &D.group[1], &D.group_cap[1], D.RB * nb * group_ld(nb)));
   GPX_RET(dist_ensure(h, &D.xloc, &D.xloc_cap, rows * d));
   GPX_RET(dist_ensure(h, &D.gid, &D.gid_cap, rows));
   GPX_RET(dist_ensure(h, &D.type, &D.type_cap, rows));
@@ -284,7 +297,8 @@ extern "C" int gpx_dist_step_panel(gpx_handle* h, int64_t k) {
   g.M = mrows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
   g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
   GPX_RET(launch_gemm_nt(h, h->s_main, g));
-  // pack this rank's panel rows densely for the all-gather
+  // pack this rank's panel rows densely for the all-gather  (writing them from the panel kernel's own tiles as a second
+  // output instead was measured in round 3: 36.6-37.0 vs 36.4 ms per one-rank N = 16384 step -- not kept)
   GPX_HIP_CHECK(h, hipMemcpy2DAsync(D.send, (size_t)nb * sizeof(double), D.L + s0 * nb * D.ld + c0, (size_t)D.ld * sizeof(double),
                                     (size_t)nb * sizeof(double), (size_t)mrows, hipMemcpyDeviceToDevice, h->s_main));
   return GPX_OK;
@@ -297,7 +311,7 @@ extern "C" int gpx_dist_step_gather(gpx_handle* h, int64_t k) {
   DistState& D = h->dist;
   const int64_t nbelow = D.RB - k - 1;
   if (nbelow <= 0) return GPX_OK;
-  hipLaunchKernelGGL(dist_unpermute_kernel, dim3((unsigned)nbelow), dim3(256), 0, h->s_main, panel_buf(D, k), D.recv, k, D.RB,
+  hipLaunchKernelGGL(dist_unpermute_kernel, dim3((unsigned)nbelow, 4u), dim3(256), 0, h->s_main, panel_buf(D, k), D.recv, k, D.RB,
                      D.P, h->nb, D.gather_stride_rows > 0 ? D.gather_stride_rows : D.chunk_rows);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
@@ -362,7 +376,7 @@ extern "C" int gpx_dist_step_gather_group(gpx_handle* h, int64_t k, int slot, in
   if (slot < 0 || slot >= GPX_DIST_GMAX || (buf != 0 && buf != 1)) { gpx_set_error(h, "gpx_dist_step_gather_group: bad slot / buffer"); return GPX_ERR_ARG; }
   const int64_t nbelow = D.RB - k - 1;
   if (nbelow <= 0) return GPX_OK;
-  hipLaunchKernelGGL(dist_unpermute_group_kernel, dim3((unsigned)nbelow), dim3(256), 0, h->s_main, D.group[buf], (int64_t)GPX_DIST_GMAX * h->nb,
+  hipLaunchKernelGGL(dist_unpermute_group_kernel, dim3((unsigned)nbelow, 4u), dim3(256), 0, h->s_main, D.group[buf], group_ld(h->nb),
                      slot, D.recv, k, D.RB, D.P, h->nb, D.gather_stride_rows > 0 ? D.gather_stride_rows : D.chunk_rows);
   GPX_HIP_CHECK(h, hipGetLastError());
   return GPX_OK;
@@ -380,7 +394,7 @@ extern "C" int gpx_dist_step_update_group(gpx_handle* h, int64_t kfirst, int64_t
   // own rows from global block cfirst on: the blocks between k+1 and cfirst have no lower tile in these columns (and on one
   // rank the launch is then the square-topped trapezoid that the 1-D tile enumeration serves without empty workgroups)
   const int64_t s0 = first_slot_after(D, D.rank, cfirst - 1);
-  const int64_t mrows = (D.nloc - s0) * nb, ldg = (int64_t)GPX_DIST_GMAX * nb;
+  const int64_t mrows = (D.nloc - s0) * nb, ldg = group_ld(nb);
   if (mrows <= 0 || ncol <= 0) return GPX_OK;
   GemmLaunch t;
   t.A = D.L + s0 * nb * D.ld + kfirst * nb; t.lda = D.ld;          // own rows: the group's panels are adjacent columns of L
