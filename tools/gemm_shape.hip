@@ -16,7 +16,7 @@ int main(int argc, char** argv) {
     const int64_t K = atoll(argv[a]);
     GemmLaunch t;
     t.A = L; t.lda = ld; t.B = L; t.ldb = ld; t.C = A; t.ldc = ld;
-    t.M = M; t.N = N; t.K = K; t.alpha = -1.0; t.beta = 1.0; t.lower = 1; t.row_off = 0; t.col_off = 0; t.b_lower_tri = 0;
+    t.M = M; t.N = N; t.K = K; t.alpha = -1.0; t.beta = getenv("BETA0") ? 0.0 : 1.0; t.lower = 1; t.row_off = 0; t.col_off = 0; t.b_lower_tri = 0;   // BETA0=1: no C read (counter calibration)
     t.small_tile = 0;
     double entries = (double)N * (N + 1) / 2.0 + (double)(M - N) * N;
     if (getenv("RECT")) {   // RECT=1: full M x N rectangle on the 64x64 kernel, RECT=2: on the one-pass 32x32 kernel (the look-ahead column updates)
