@@ -13,8 +13,9 @@ echo "HEAD ${GPX_HEAD:-?}  $(date -u +%FT%TZ)" > $OUT/STAMP
 # the diagnostic builds the tools below need (git-ignored binaries: a fresh checkout does not have them)
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 [ -x tools/peaks ] || $HIPCC --offload-arch=gfx950 -O3 -o tools/peaks tools/peaks.hip > $OUT/build_tools.log 2>&1
-[ -x tools/potrf_stamps ] || $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o tools/potrf_stamps tools/potrf_stamps.hip >> $OUT/build_tools.log 2>&1
-[ -f tools/libgpx_hip_tl.so ] || make -C gpax_amd/csrc timeline -j8 >> $OUT/build_tools.log 2>&1
+# (these two include the library's sources: always rebuilt, a stale diagnostic build would describe another library)
+$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -o tools/potrf_stamps tools/potrf_stamps.hip >> $OUT/build_tools.log 2>&1
+rm -f tools/libgpx_hip_tl.so; rm -rf gpax_amd/csrc/build_tl; make -C gpax_amd/csrc timeline -j8 >> $OUT/build_tools.log 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"; tail -c 200 $OUT/bench.json; echo
 cd /tmp && export TMPDIR=/tmp
