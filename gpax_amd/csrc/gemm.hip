@@ -59,6 +59,16 @@ __device__ __forceinline__ int64_t tile_global_row(const GemmArgs& g, int64_t m0
 }
 
 #define GEMM_BK 32
+// Wave priorities (s_setprio): the chain's band kernel and the panel stream's kernels share their SIMDs with bulk-update
+// waves, which are throughput work -- their waves issue ahead of those.  Same box, alternated: N = 2048 0.574-0.578 vs
+// 0.578-0.582 ms per step (one run 0.676), N = 4096 1.455-1.477 vs 1.471-1.486, N = 8192 a tie; (2, 3) instead of (1, 2) no
+// better (profiles/r03_wave_priority_ab.txt).
+#ifndef GEMM_Q_PRIO
+#define GEMM_Q_PRIO 1      // the panel stream's kernels: panel solve, look-ahead column updates
+#endif
+#ifndef GEMM_BAND_PRIO
+#define GEMM_BAND_PRIO 2   // the chain's band kernel
+#endif
 #ifndef GEMM_MAIN_WAVES
 #define GEMM_MAIN_WAVES 3   // waves per SIMD the register budget of gemm_nt_kernel is sized for (168 VGPRs: three workgroups per CU)
 #endif
@@ -141,6 +151,7 @@ __global__ __launch_bounds__(256, GEMM_MAIN_WAVES) void gemm_nt_kernel(GemmArgs 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   GEMM_TL(ROLE == 1 ? 8 : 4, g.M, g.N * 1000000 + g.K);
+  if constexpr (ROLE == 1) __builtin_amdgcn_s_setprio(GEMM_Q_PRIO);
   batch_offset(g);
   int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
   bool first_part = false;   // bulk instantiation: this tile lies in the first block column and publishes itself
@@ -561,6 +572,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_onepass_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
   const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
   if (g.lower && (tile_global_row(g, m0) + 31 < g.col_off + n0)) return;
+  __builtin_amdgcn_s_setprio(GEMM_Q_PRIO);
   batch_offset(g);
   onepass_body<K>(g, m0, n0, As, Bs);
 }
@@ -620,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void chain_band_kernel(BandArgs b) {
   __shared__ __attribute__((aligned(16))) double As[32 * (K / 2 + 4)];
   __shared__ __attribute__((aligned(16))) double Bs[32 * (K / 2 + 4)];
   constexpr int NT = K / 32;
+  __builtin_amdgcn_s_setprio(GEMM_BAND_PRIO);
   const int row = (int)blockIdx.y / NT;
   const int64_t m0 = (int64_t)((int)blockIdx.y % NT) * 32, n0 = (int64_t)blockIdx.x * 32;
   const int64_t z = blockIdx.z;
