@@ -759,26 +759,38 @@ extern "C" int gpx_fit_factor(gpx_handle* h, const gpx_kernel_params* p, double*
 
 // X L^T = S for `srows` right-hand-side ROWS (S, X: srows x npad, row-major): right-looking,
 //   X_k = S_k W_k^T ;  S_j -= X_k L_jk^T  (j > k)   -- GEMMs only.
+// X = S L^-T for `srows` right-hand-side rows against the cached factor (the cho_solve of gpax/gp.py:297-299 as GEMMs against
+// W_k = L_kk^-1): right-looking over block columns, the columns behind a GROUP of four or eight updated in one K = G nb pass (inside
+// the group every solved column updates the group's remaining ones at K = nb) -- the bulk kernel runs K >= 512 at 55-65 instead
+// of 44 TFLOP/s and the right-hand sides are read and written once per G panels (round 3; M = 10 000 rows against
+// N = 8192: profiles/r03_posterior_cached_factor.txt).
 static int solve_rows(gpx_handle* h, double* S, double* X, int64_t srows) {
   const int64_t nb = h->nb, npad = h->npad, ld = h->ld, nblk = npad / nb;
+  static const int64_t g_env = getenv("GPX_SOLVE_GROUP") ? std::max(1, atoi(getenv("GPX_SOLVE_GROUP"))) : 0;   // diagnostic (1: round 2's column-by-column form)
+  const int64_t G = g_env ? g_env : (nblk >= 32 ? 8 : 4);   // eight panels per pass from N = 4096 on (measured: -2..3 % against four; +2 % at N = 2048)
   hipStream_t s = h->s_main;
-  for (int64_t k = 0; k < nblk; ++k) {
-    const int64_t c0 = k * nb, r0 = c0 + nb;
-    GemmLaunch g;
-    g.A = S + c0; g.lda = npad;
-    g.B = h->d_W + k * nb * nb; g.ldb = nb;
-    g.C = X + c0; g.ldc = npad;
-    g.M = srows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
-    g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
-    GPX_RET(launch_gemm_nt(h, s, g));
-    if (r0 >= npad) break;
+  auto update = [&](int64_t kfirst, int64_t npan, int64_t cfirst, int64_t ncolblk) -> int {   // S[:, cols) -= X[:, panels) L[cols, panels)^T
     GemmLaunch u;
-    u.A = X + c0; u.lda = npad;
-    u.B = h->d_L + r0 * ld + c0; u.ldb = ld;
-    u.C = S + r0; u.ldc = npad;
-    u.M = srows; u.N = npad - r0; u.K = nb; u.alpha = -1.0; u.beta = 1.0;
+    u.A = X + kfirst * nb; u.lda = npad;
+    u.B = h->d_L + cfirst * nb * ld + kfirst * nb; u.ldb = ld;
+    u.C = S + cfirst * nb; u.ldc = npad;
+    u.M = srows; u.N = ncolblk * nb; u.K = npan * nb; u.alpha = -1.0; u.beta = 1.0;
     u.lower = 0; u.row_off = 0; u.col_off = 0; u.b_lower_tri = 0; u.small_tile = srows <= 64 ? 1 : 0;
-    GPX_RET(launch_gemm_nt(h, s, u));
+    return launch_gemm_nt(h, s, u);
+  };
+  for (int64_t g0 = 0; g0 < nblk; g0 += G) {
+    const int64_t gend = std::min(nblk, g0 + G);
+    for (int64_t k = g0; k < gend; ++k) {
+      GemmLaunch g;
+      g.A = S + k * nb; g.lda = npad;
+      g.B = h->d_W + k * nb * nb; g.ldb = nb;
+      g.C = X + k * nb; g.ldc = npad;
+      g.M = srows; g.N = nb; g.K = nb; g.alpha = 1.0; g.beta = 0.0;
+      g.lower = 0; g.row_off = 0; g.col_off = 0; g.b_lower_tri = 1; g.small_tile = 1;
+      GPX_RET(launch_gemm_nt(h, s, g));
+      if (k + 1 < gend) GPX_RET(update(k, 1, k + 1, gend - (k + 1)));
+    }
+    if (gend < nblk) GPX_RET(update(g0, gend - g0, gend, nblk - gend));
   }
   return GPX_OK;
 }
