@@ -260,6 +260,10 @@ struct SplitSchedule {
     // the gradient path doubles the bulk stream's work (identity border rows, K^-1 accumulation): it is bound by
     // that stream almost to the end, so its bulk updates are grouped down to 8 remaining block columns
     pair_min = kinv ? std::min<int64_t>(h->pair_min, 8) : h->pair_min; quad_min = h->quad_min;
+    // more test points than training points (config C5: 10 000 candidates against N = 8192): the border rows are most of every
+    // bulk launch and the step is bound by that stream to the end, like the gradient path's -- grouped down to 8 / 16 remaining
+    // block columns: 17.5 -> 16.9-17.0 ms per step at C5's shape (tools/c5_opts.py); at M = N it is a tie
+    if (!kinv && tri_base < 0 && M.rows_total - M.npad >= M.npad) { pair_min = std::min<int64_t>(pair_min, 8); quad_min = std::min<int64_t>(quad_min, 16); }
     // Batches of four or more draws are throughput-bound from the first step to the last: the chain's latency hides behind
     // the other draws' work, so the bulk updates are grouped throughout (K = g nb passes run the bulk kernel at 48-53
     // instead of 40 TFLOP/s and cut the passes over the trailing matrices g-fold).  Measured at N = 4096, 16 draws:
